@@ -1,0 +1,209 @@
+/*
+ * rfm_hip.h -- C ABI of librfm_hip.so, the MI355X (gfx950) implementation of the
+ * FM / MF mini-batch SGD path of tatsuki1107/Relevance-FactorizationMachine.
+ *
+ * The reference has no FFI of its own (it is pure Python); the boundary it
+ * offers is the Python class surface of src/base.py, src/fm.py, src/mf.py and
+ * utils/optimizer.py.  Each entry point below names the reference code
+ * (file:line, relative to the reference root) whose arithmetic it replaces.
+ * The Python mirror of that surface (relevance_factorizationmachine_amd/fm.py,
+ * mf.py) calls these through ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - every call returns int32: RFM_OK or an RFM_ERR_* class; the message is
+ *    fetched with rfm_last_error() (thread-local).  No C++ exception crosses.
+ *  - pointers named d_* are DEVICE pointers owned by the caller (torch tensors
+ *    in the Python mirror); h_* are HOST pointers.  The library allocates only
+ *    ctx-/plan-owned scratch and frees it in the matching destroy call.
+ *  - calls that take a ctx are asynchronous on the ctx's HIP stream; use
+ *    rfm_sync() (or synchronise the stream yourself) before reading results.
+ *  - all parameters and activations are float64 (the reference computes in
+ *    NumPy float64); CSR column indices and row ids are int32, CSR row
+ *    pointers int64, labels are passed as float64 {0,1}.
+ *  - one ctx per (host thread, device); no global mutable state.
+ */
+#ifndef RFM_HIP_H
+#define RFM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFM_VERSION 100 /* 0.1.0 */
+
+enum {
+  RFM_OK = 0,
+  RFM_ERR_BAD_ARG = 1, /* caller error: shapes, null pointers, unsupported k */
+  RFM_ERR_HIP = 2,     /* a HIP runtime call or kernel launch failed */
+  RFM_ERR_NO_DEVICE = 3,
+  RFM_ERR_INTERNAL = 4
+};
+
+/* limits of this build */
+#define RFM_MAX_FACTORS 1024
+
+typedef struct rfm_ctx rfm_ctx;
+typedef struct rfm_fm_plan rfm_fm_plan;
+typedef struct rfm_mf_sched rfm_mf_sched;
+
+/* ---- diagnostics ------------------------------------------------------- */
+int32_t rfm_version(void);
+/* copies the calling thread's last error message (NUL-terminated) */
+int32_t rfm_last_error(char* buf, size_t n);
+
+/* ---- context ----------------------------------------------------------- */
+/* hip_stream: a hipStream_t to run on (NULL = the device's default stream). */
+int32_t rfm_create(int32_t device, void* hip_stream, rfm_ctx** out);
+int32_t rfm_destroy(rfm_ctx* ctx);
+int32_t rfm_sync(rfm_ctx* ctx);
+
+/* ---- per-kernel timing (HIP events on the ctx stream) ---------------------
+ * Between rfm_profile_begin and rfm_profile_end every FM training step records
+ * events around its launches.  rfm_profile_end synchronises and returns, per
+ * phase, the summed milliseconds and the number of launches:
+ *   phase 0 forward (+residual, Q, marks)   phase 1 column gradient/update
+ *   phase 2 finalize (long columns, w0)     phase 3 whole step
+ * h_ms[4], h_count[4]. */
+int32_t rfm_profile_begin(rfm_ctx* ctx);
+int32_t rfm_profile_end(rfm_ctx* ctx, double* h_ms, int64_t* h_count);
+
+/* ---- mini-batch selection (host) ---------------------------------------
+ * Replaces sklearn.utils.resample(X, y, p, replace=False, n_samples=B,
+ * random_state=epoch) as called at src/fm.py:72-79 and src/mf.py:88-95:
+ * legacy MT19937 seeded with the iteration number, Fisher-Yates shuffle of
+ * arange(n_rows) with NumPy's masked-rejection interval draw, first B ids.
+ * h_out_ids[(e - epoch_begin) * batch_size + t], bit-identical to NumPy.
+ * RFM_ERR_BAD_ARG when batch_size > n_rows (the reference raises ValueError). */
+int32_t rfm_sample_batches(int64_t n_rows, int64_t batch_size, int64_t epoch_begin,
+                           int64_t n_epochs, int32_t* h_out_ids, int32_t n_threads);
+
+/* ---- FM: forward / scores ----------------------------------------------
+ * Replaces FactorizationMachines.predict (src/fm.py:114-133) with _sigmoid
+ * (src/base.py:63-66): out[t] = sigmoid(clip(w0 + sum_i w_i x_ti
+ *   + 0.5 * sum_f[(sum_i v_if x_ti)^2 - sum_i v_if^2 x_ti^2], +-700))
+ * for row r = d_row_ids ? d_row_ids[t] : t of the CSR matrix. */
+int32_t rfm_fm_forward(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_indices,
+                       const double* d_values, const int32_t* d_row_ids, int64_t n_rows,
+                       const double* d_w0, const double* d_w, const double* d_V,
+                       int64_t n_features, int32_t n_factors, double* d_out_pred);
+
+/* Replaces _cross_entropy_loss (src/base.py:37-61):
+ * *d_out = -(1/n) * sum_t[(y/p) log(pred_t + eps) + (1 - y/p) log(1 - pred_t + eps)]
+ * with y, p taken at row d_row_ids[t] (or t) and pred at t.  Deterministic
+ * two-pass reduction. */
+int32_t rfm_ips_logloss(rfm_ctx* ctx, const double* d_y, const double* d_pred,
+                        const double* d_pscore, const int32_t* d_row_ids, int64_t n_rows,
+                        double eps, double* d_out_loss);
+
+/* Fused forward + loss of the rows (src/fm.py:90-102): scores never leave the
+ * chip.  d_out_pred may be NULL. */
+int32_t rfm_fm_forward_loss(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_indices,
+                            const double* d_values, const double* d_y, const double* d_pscore,
+                            const int32_t* d_row_ids, int64_t n_rows, const double* d_w0,
+                            const double* d_w, const double* d_V, int64_t n_features,
+                            int32_t n_factors, double eps, double* d_out_pred,
+                            double* d_out_loss);
+
+/* ---- FM: training plan --------------------------------------------------
+ * One-time (per fit) column-major view of the training CSR used by the
+ * atomic-free gradient: built on the host from the caller's HOST CSR arrays,
+ * stored in plan-owned device memory.  max_batch bounds the batch size of
+ * later steps.  hot_min_count: a column whose expected number of entries per
+ * batch (its training frequency * max_batch / n_rows) reaches this value is
+ * accumulated on chip per row tile instead of through its column list
+ * (0 = library default, <0 = never). */
+int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t* h_indices,
+                           const double* h_values, int64_t n_rows, int64_t n_features,
+                           int32_t n_factors, int64_t max_batch, int32_t hot_min_count,
+                           rfm_fm_plan** out);
+int32_t rfm_fm_plan_destroy(rfm_fm_plan* plan);
+/* h_out[0]=n_work_items, [1]=n_split_columns, [2]=n_hot_columns, [3]=nnz,
+ * [4]=device bytes owned by the plan */
+int32_t rfm_fm_plan_info(const rfm_fm_plan* plan, int64_t* h_out5);
+
+/* ---- FM: one training step ----------------------------------------------
+ * Replaces lines src/fm.py:80-88 with _update_w0/_update_w/_update_V
+ * (src/fm.py:135-187) and SGD.update (utils/optimizer.py:56-64) for the batch
+ * rows d_row_ids[0..batch): residual e = y/p - predict(old params); batch-SUM
+ * gradients (no 1/|B|); w0, w, V updated in place with lr.  The CSR arrays are
+ * the device copy of the matrix the plan was built from. */
+int32_t rfm_fm_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
+                    const int32_t* d_indices, const double* d_values, const double* d_y,
+                    const double* d_pscore, const int32_t* d_row_ids, int64_t batch,
+                    double* d_w0, double* d_w, double* d_V, double lr);
+
+/* Same gradients, not applied: d_grad = [G_V (n*k) | g_w (n) | g_w0 (1)] for
+ * the given rows (a rank's shard of the batch).  Every element of d_grad is
+ * written.  For the data-parallel path: all-reduce d_grad, then rfm_fm_apply. */
+int32_t rfm_fm_grad(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
+                    const int32_t* d_indices, const double* d_values, const double* d_y,
+                    const double* d_pscore, const int32_t* d_row_ids, int64_t batch,
+                    const double* d_w0, const double* d_w, const double* d_V, double* d_grad);
+/* theta -= lr * grad over the same [V | w | w0] layout (utils/optimizer.py:56-64). */
+int32_t rfm_fm_apply(rfm_ctx* ctx, double* d_w0, double* d_w, double* d_V,
+                     const double* d_grad, int64_t n_features, int32_t n_factors, double lr);
+
+/* ---- FM: the fit() loop --------------------------------------------------
+ * Replaces the body of FactorizationMachines.fit (src/fm.py:71-102) for
+ * iterations [0, n_iters): step on batch d_ids[it*batch ...], then the train
+ * loss of the SAME batch with the new parameters, then the validation loss.
+ * d_out_train_loss / d_out_val_loss receive one value per iteration (either
+ * may be NULL to skip that forward).  Everything is enqueued on the ctx
+ * stream; nothing synchronises. */
+int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
+                     const int32_t* d_indices, const double* d_values, const double* d_y,
+                     const double* d_pscore, const int32_t* d_ids, int64_t batch,
+                     int64_t n_iters, double* d_w0, double* d_w, double* d_V, double lr,
+                     const int64_t* d_val_indptr, const int32_t* d_val_indices,
+                     const double* d_val_values, const double* d_val_y,
+                     const double* d_val_pscore, int64_t n_val, double eps,
+                     double* d_out_train_loss, double* d_out_val_loss);
+
+/* ---- MF ------------------------------------------------------------------
+ * Replaces LogisticMatrixFactorization.predict/_predict_pair
+ * (src/mf.py:136-170): out[t] = sigmoid(clip(P_u . Q_i + b_u + b_i + b)). */
+int32_t rfm_mf_predict(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d_items,
+                       const int32_t* d_row_ids, int64_t n_rows, const double* d_P,
+                       const double* d_Q, const double* d_bu, const double* d_bi, double b,
+                       int32_t n_factors, double* d_out_pred);
+int32_t rfm_mf_predict_loss(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d_items,
+                            const double* d_y, const double* d_pscore,
+                            const int32_t* d_row_ids, int64_t n_rows, const double* d_P,
+                            const double* d_Q, const double* d_bu, const double* d_bi,
+                            double b, int32_t n_factors, double eps, double* d_out_pred,
+                            double* d_out_loss);
+
+/* Order-preserving schedule of one batch (host): the reference updates the
+ * batch strictly sequentially (src/mf.py:97-108).  Example s must run after
+ * the latest earlier example sharing its user or its item; level(s) = 1 +
+ * max(level of those).  Examples of one level touch disjoint rows, so running
+ * the levels in order reproduces the sequential result exactly.
+ * h_users/h_items: ids of the batch in batch order.  h_order[batch] receives
+ * the batch positions grouped by level (ascending position inside a level),
+ * h_level_ptr[n_levels+1] (capacity batch+1) the group boundaries;
+ * *h_n_levels the number of levels. */
+int32_t rfm_mf_schedule(const int32_t* h_users, const int32_t* h_items, int64_t batch,
+                        int32_t n_users, int32_t n_items, int32_t* h_order,
+                        int32_t* h_level_ptr, int32_t* h_n_levels);
+
+/* Replaces the inner loop src/mf.py:97-108 with _update_P/_Q/_b_u/_b_i
+ * (src/mf.py:172-216): for each level in order, for each example of the level
+ * (independent): err = y/p - predict; P_u -= lr(-err Q_i + reg P_u); Q_i -=
+ * lr(-err P_u(new) + reg Q_i); b_u, b_i likewise.  d_order/h_level_ptr from
+ * rfm_mf_schedule (level_ptr both on the host, to size the launches, and on
+ * the device); d_pos_rows[s] is the training row of batch position s. */
+int32_t rfm_mf_sgd_levels(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d_items,
+                          const double* d_y, const double* d_pscore,
+                          const int32_t* d_pos_rows, const int32_t* d_order,
+                          const int32_t* h_level_ptr, const int32_t* d_level_ptr,
+                          int32_t n_levels, double* d_P,
+                          double* d_Q, double* d_bu, double* d_bi, double b,
+                          int32_t n_factors, double lr, double reg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFM_HIP_H */

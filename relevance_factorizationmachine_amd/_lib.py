@@ -1,0 +1,144 @@
+"""ctypes binding of ``librfm_hip.so`` (C ABI declared in ``include/rfm_hip.h``).
+
+The shared library is built in-tree by :func:`build` (``hipcc
+--offload-arch=gfx950``); there is no CPU fallback -- if the library cannot be
+loaded, or no GPU is visible when a device call is made, the caller gets an
+exception, never a silently different code path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+from typing import List, Optional
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "librfm_hip.so")
+SOURCES = ["rfm_capi.hip", "rfm_fm.hip", "rfm_mf.hip", "rfm_host.cpp"]
+HEADERS = [os.path.join(CSRC, "rfm_common.h"),
+           os.path.join(os.path.dirname(PKG_DIR), "include", "rfm_hip.h")]
+
+RFM_OK, RFM_ERR_BAD_ARG, RFM_ERR_HIP, RFM_ERR_NO_DEVICE, RFM_ERR_INTERNAL = range(5)
+
+
+class RfmError(RuntimeError):
+    """A call into librfm_hip.so failed (HIP error, no device, internal)."""
+
+
+def _hipcc() -> Optional[str]:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.exists(d) and os.path.getmtime(d) > built for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP extension for gfx950 in-tree; returns the .so path."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = _hipcc()
+    if hipcc is None:
+        raise RfmError("hipcc not found: cannot build librfm_hip.so (set HIPCC or install ROCm)")
+    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+           "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread"]
+    if verbose:
+        print(" ".join(cmd))
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise RfmError("building librfm_hip.so failed:\n" + proc.stdout + proc.stderr)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+_i32, _i64, _f64, _vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
+
+# name -> argtypes; every function returns int32.  Mirrors include/rfm_hip.h.
+SIGNATURES = {
+    "rfm_version": [],
+    "rfm_last_error": [C.c_char_p, C.c_size_t],
+    "rfm_create": [_i32, _vp, C.POINTER(_vp)],
+    "rfm_destroy": [_vp],
+    "rfm_sync": [_vp],
+    "rfm_profile_begin": [_vp],
+    "rfm_profile_end": [_vp, _vp, _vp],
+    "rfm_sample_batches": [_i64, _i64, _i64, _i64, _vp, _i32],
+    "rfm_fm_forward": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp],
+    "rfm_ips_logloss": [_vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp],
+    "rfm_fm_forward_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32,
+                            _f64, _vp, _vp],
+    "rfm_fm_plan_create": [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _i32, C.POINTER(_vp)],
+    "rfm_fm_plan_destroy": [_vp],
+    "rfm_fm_plan_info": [_vp, _vp],
+    "rfm_fm_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f64],
+    "rfm_fm_grad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "rfm_fm_apply": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64],
+    "rfm_fm_train": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _f64,
+                     _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp],
+    "rfm_mf_predict": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _i32, _vp],
+    "rfm_mf_predict_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _i32,
+                            _f64, _vp, _vp],
+    "rfm_mf_schedule": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, C.POINTER(_i32)],
+    "rfm_mf_sgd_levels": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
+                          _f64, _i32, _f64, _f64],
+}
+
+_lib = None
+
+
+def exported_symbols() -> List[str]:
+    return list(SIGNATURES)
+
+
+def load():
+    """Load (building first if the in-tree .so is missing or stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = LIB_PATH
+    if _stale():
+        if _hipcc() is not None:
+            path = build()
+        elif not os.path.exists(LIB_PATH):
+            raise RfmError(
+                f"{LIB_PATH} is missing and hipcc is not available to build it; "
+                "the HIP extension is required (there is no CPU fallback)")
+    try:
+        lib = C.CDLL(path)
+    except OSError as exc:
+        raise RfmError(f"cannot load {path}: {exc}") from exc
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = header/library mismatch
+        fn.argtypes = argtypes
+        fn.restype = _i32
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(1024)
+    load().rfm_last_error(buf, len(buf))
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    """Map the ABI's error classes to Python exceptions (bad argument ->
+    ValueError, as the reference raises from ``resample``)."""
+    if rc == RFM_OK:
+        return
+    msg = last_error()
+    if rc == RFM_ERR_BAD_ARG:
+        raise ValueError(msg)
+    raise RfmError(f"librfm_hip error {rc}: {msg}")

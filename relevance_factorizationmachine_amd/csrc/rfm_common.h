@@ -1,0 +1,112 @@
+// Shared host-side plumbing of librfm_hip.so: error reporting across the C ABI,
+// the context object and small device-memory helpers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rfm_hip.h"
+
+namespace rfm {
+
+struct Error : std::runtime_error {
+  int32_t code;
+  Error(int32_t c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+void set_last_error(const std::string& msg);
+
+[[noreturn]] inline void fail(int32_t code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  throw Error(code, buf);
+}
+
+#define RFM_HIP_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess)                                                                \
+      ::rfm::fail(RFM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                  __FILE__, __LINE__);                                                   \
+  } while (0)
+
+#define RFM_REQUIRE(cond, ...)                                   \
+  do {                                                           \
+    if (!(cond)) ::rfm::fail(RFM_ERR_BAD_ARG, __VA_ARGS__);      \
+  } while (0)
+
+// Runs fn, maps exceptions to the ABI's int32 error classes.
+template <class Fn>
+inline int32_t guarded(Fn&& fn) {
+  try {
+    fn();
+    return RFM_OK;
+  } catch (const Error& e) {
+    set_last_error(e.what());
+    return e.code;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return RFM_ERR_INTERNAL;
+  } catch (...) {
+    set_last_error("unknown error");
+    return RFM_ERR_INTERNAL;
+  }
+}
+
+// plan-/ctx-owned device buffer
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  void alloc(size_t n) {
+    release();
+    if (n == 0) n = 16;
+    RFM_HIP_CHECK(hipMalloc(&p, n));
+    bytes = n;
+  }
+  void ensure(size_t n) {
+    if (n > bytes) alloc(n);
+  }
+  template <class T>
+  T* as() const {
+    return static_cast<T*>(p);
+  }
+};
+
+}  // namespace rfm
+
+struct rfm_ctx {
+  int32_t device = 0;
+  hipStream_t stream = nullptr;
+  int32_t n_cu = 256;
+  rfm::DevBuf loss_partials;  // per-block partial sums of the loss reduction
+  rfm::DevBuf pred_scratch;   // scores when the caller does not want them
+  // per-kernel timing (rfm_profile_begin/end): 4 events per recorded step
+  bool profiling = false;
+  std::vector<hipEvent_t> prof_events;
+  void prof_mark() {
+    if (!profiling) return;
+    hipEvent_t e;
+    RFM_HIP_CHECK(hipEventCreate(&e));
+    RFM_HIP_CHECK(hipEventRecord(e, stream));
+    prof_events.push_back(e);
+  }
+};

@@ -1,0 +1,180 @@
+// Host-side pieces of librfm_hip.so: error state, the exact mini-batch sampler
+// and the order-preserving MF schedule.  No device code here.
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
+#include "rfm_common.h"
+
+namespace rfm {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+
+// --------------------------------------------------------------------------
+// MT19937 as NumPy's legacy RandomState runs it (numpy/random/src/mt19937).
+// Restated from the published algorithm (Matsumoto & Nishimura 1998) and
+// checked bit-for-bit against numpy.random.RandomState in the tests.
+// --------------------------------------------------------------------------
+struct Mt19937 {
+  static constexpr int N = 624, M = 397;
+  uint32_t key[N];
+  int pos;
+
+  explicit Mt19937(uint32_t seed) {
+    for (int i = 0; i < N; ++i) {
+      key[i] = seed;
+      seed = 1812433253u * (seed ^ (seed >> 30)) + uint32_t(i) + 1u;
+    }
+    pos = N;
+  }
+
+  void refill() {
+    constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
+    int i = 0;
+    for (; i < N - M; ++i) {
+      uint32_t y = (key[i] & UPPER) | (key[i + 1] & LOWER);
+      key[i] = key[i + M] ^ (y >> 1) ^ ((0u - (y & 1u)) & MATRIX_A);
+    }
+    for (; i < N - 1; ++i) {
+      uint32_t y = (key[i] & UPPER) | (key[i + 1] & LOWER);
+      key[i] = key[i + (M - N)] ^ (y >> 1) ^ ((0u - (y & 1u)) & MATRIX_A);
+    }
+    uint32_t y = (key[N - 1] & UPPER) | (key[0] & LOWER);
+    key[N - 1] = key[M - 1] ^ (y >> 1) ^ ((0u - (y & 1u)) & MATRIX_A);
+    pos = 0;
+  }
+
+  inline uint32_t next32() {
+    if (pos == N) refill();
+    uint32_t y = key[pos++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+  }
+
+  // NumPy's random_interval for max <= 0xffffffff: mask to the next power of
+  // two minus one, redraw while above max.
+  inline uint32_t interval(uint32_t max) {
+    if (max == 0) return 0;
+    uint32_t mask = max;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    uint32_t v;
+    while ((v = (next32() & mask)) > max) {
+    }
+    return v;
+  }
+};
+
+// RandomState(epoch).shuffle(arange(n)) -> first batch entries.
+static void sample_one(int64_t n_rows, int64_t batch, uint32_t seed, int32_t* scratch,
+                       int32_t* out) {
+  for (int64_t i = 0; i < n_rows; ++i) scratch[i] = int32_t(i);
+  Mt19937 rng(seed);
+  for (int64_t i = n_rows - 1; i >= 1; --i) {
+    uint32_t j = rng.interval(uint32_t(i));
+    int32_t tmp = scratch[i];
+    scratch[i] = scratch[j];
+    scratch[j] = tmp;
+  }
+  std::memcpy(out, scratch, size_t(batch) * sizeof(int32_t));
+}
+
+}  // namespace rfm
+
+using namespace rfm;
+
+extern "C" {
+
+int32_t rfm_version(void) { return RFM_VERSION; }
+
+int32_t rfm_last_error(char* buf, size_t n) {
+  if (!buf || n == 0) return RFM_ERR_BAD_ARG;
+  std::snprintf(buf, n, "%s", g_last_error.c_str());
+  return RFM_OK;
+}
+
+int32_t rfm_sample_batches(int64_t n_rows, int64_t batch_size, int64_t epoch_begin,
+                           int64_t n_epochs, int32_t* h_out_ids, int32_t n_threads) {
+  return guarded([&] {
+    RFM_REQUIRE(n_rows > 0 && n_rows < (int64_t(1) << 31), "n_rows=%lld out of range",
+                (long long)n_rows);
+    RFM_REQUIRE(batch_size > 0, "batch_size must be positive");
+    RFM_REQUIRE(batch_size <= n_rows,
+                "Cannot sample %lld out of arrays with dim %lld when replace is False",
+                (long long)batch_size, (long long)n_rows);
+    RFM_REQUIRE(epoch_begin >= 0 && epoch_begin + n_epochs <= (int64_t(1) << 32),
+                "epoch seeds must fit 32 bits");
+    RFM_REQUIRE(n_epochs >= 0 && (n_epochs == 0 || h_out_ids), "null output");
+    if (n_epochs == 0) return;
+    int nt = n_threads > 0 ? n_threads : int(std::thread::hardware_concurrency());
+    nt = std::max(1, std::min<int>(nt, int(std::min<int64_t>(n_epochs, 256))));
+    std::atomic<int64_t> next{0};
+    auto worker = [&] {
+      std::vector<int32_t> scratch(static_cast<size_t>(n_rows), 0);
+      for (;;) {
+        int64_t e = next.fetch_add(1);
+        if (e >= n_epochs) break;
+        sample_one(n_rows, batch_size, uint32_t(epoch_begin + e), scratch.data(),
+                   h_out_ids + e * batch_size);
+      }
+    };
+    if (nt == 1) {
+      worker();
+    } else {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < nt; ++t) pool.emplace_back(worker);
+      for (auto& th : pool) th.join();
+    }
+  });
+}
+
+int32_t rfm_mf_schedule(const int32_t* h_users, const int32_t* h_items, int64_t batch,
+                        int32_t n_users, int32_t n_items, int32_t* h_order,
+                        int32_t* h_level_ptr, int32_t* h_n_levels) {
+  return guarded([&] {
+    RFM_REQUIRE(h_users && h_items && h_order && h_level_ptr && h_n_levels, "null pointer");
+    RFM_REQUIRE(batch >= 0 && batch < (int64_t(1) << 31), "batch out of range");
+    // last level seen per user / item; only touched entries are reset afterwards
+    static thread_local std::vector<int32_t> last_u, last_i;
+    if (int64_t(last_u.size()) < n_users) last_u.assign(size_t(n_users), -1);
+    if (int64_t(last_i.size()) < n_items) last_i.assign(size_t(n_items), -1);
+    std::vector<int32_t> level(static_cast<size_t>(batch), 0);
+    int32_t n_levels = 0;
+    bool bad = false;
+    for (int64_t s = 0; s < batch; ++s) {
+      int32_t u = h_users[s], i = h_items[s];
+      if (u < 0 || u >= n_users || i < 0 || i >= n_items) {
+        bad = true;
+        break;
+      }
+      int32_t lv = std::max(last_u[u], last_i[i]) + 1;
+      level[s] = lv;
+      last_u[u] = lv;
+      last_i[i] = lv;
+      n_levels = std::max(n_levels, lv + 1);
+    }
+    for (int64_t s = 0; s < batch; ++s) {
+      int32_t u = h_users[s], i = h_items[s];
+      if (u >= 0 && u < n_users) last_u[u] = -1;
+      if (i >= 0 && i < n_items) last_i[i] = -1;
+    }
+    RFM_REQUIRE(!bad, "user/item id out of range");
+    // stable counting sort of batch positions by level
+    std::vector<int32_t> cnt(static_cast<size_t>(n_levels) + 1, 0);
+    for (int64_t s = 0; s < batch; ++s) cnt[size_t(level[s]) + 1]++;
+    for (int32_t l = 0; l < n_levels; ++l) cnt[size_t(l) + 1] += cnt[size_t(l)];
+    for (int32_t l = 0; l <= n_levels; ++l) h_level_ptr[l] = cnt[size_t(l)];
+    for (int64_t s = 0; s < batch; ++s) h_order[cnt[size_t(level[s])]++] = int32_t(s);
+    *h_n_levels = n_levels;
+  });
+}
+
+}  // extern "C"

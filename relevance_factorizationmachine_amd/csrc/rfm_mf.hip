@@ -1,0 +1,430 @@
+// Logistic-MF kernels for gfx950 and their C-ABI launchers.
+//
+// Layout in HBM: P[n_users][k], Q[n_items][k] row-major f64 (the reference's
+// NumPy layout), b_u[n_users], b_i[n_items]; the (user, item) pairs of the log
+// are two int32 arrays.  A pair is handled by LPR consecutive lanes (same
+// factor-to-lane map as the FM kernels): k=128 -> 64 lanes x 16 bytes.
+//
+// Training keeps the reference's strictly sequential per-example semantics
+// (src/mf.py:97-108) through the level schedule of rfm_mf_schedule: examples
+// of one level touch disjoint rows of P, Q, b_u, b_i.  Levels with many
+// examples get a grid-wide launch each; runs of small levels are executed by
+// ONE workgroup that walks the levels with a barrier in between, so a batch
+// whose popular item forms a long chain costs one launch, not one per level.
+#include <algorithm>
+#include <cmath>
+
+#include "rfm_common.h"
+
+namespace rfm {
+
+constexpr int kMfBlock = 256;
+constexpr int kSeqBlock = 1024;
+constexpr double kMfLogitClip = 700.0;  // src/base.py:65
+
+template <int LPR>
+__device__ inline double mf_group_sum(double v) {
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, LPR);
+  return v;
+}
+
+template <int VEC>
+struct MfPack;
+template <>
+struct MfPack<1> {
+  double v[1];
+  __device__ inline void load(const double* p) { v[0] = *p; }
+  __device__ inline void store(double* p) const { *p = v[0]; }
+};
+template <>
+struct MfPack<2> {
+  double v[2];
+  __device__ inline void load(const double* p) {
+    const double2 t = *reinterpret_cast<const double2*>(p);
+    v[0] = t.x;
+    v[1] = t.y;
+  }
+  __device__ inline void store(double* p) const {
+    *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]);
+  }
+};
+
+__device__ inline double mf_sigmoid(double z) {
+  z = fmin(fmax(z, -kMfLogitClip), kMfLogitClip);
+  return 1.0 / (1.0 + exp(-z));
+}
+
+struct MfPredArgs {
+  const int32_t* users;
+  const int32_t* items;
+  const int32_t* row_ids;  // nullable
+  int64_t n_rows;
+  const double* P;
+  const double* Q;
+  const double* bu;
+  const double* bi;
+  double b;
+  int32_t k;
+  const double* y;
+  const double* pscore;
+  double* out_pred;      // nullable
+  double* loss_partial;  // nullable
+  double eps;
+};
+
+template <int LPR, int VEC, int NC>
+__global__ __launch_bounds__(kMfBlock) void mf_predict_kernel(MfPredArgs a) {
+  constexpr int GPB = kMfBlock / LPR;
+  __shared__ double lds[kMfBlock];
+  const int tid = threadIdx.x;
+  const int l = tid % LPR;
+  const int g = tid / LPR;
+  const int k = a.k;
+  double loss_acc = 0.0;
+  for (int64_t base = int64_t(blockIdx.x) * GPB; base < a.n_rows;
+       base += int64_t(gridDim.x) * GPB) {
+    const int64_t t = base + g;
+    const bool valid = t < a.n_rows;
+    int64_t r = 0;
+    int32_t u = 0, i = 0;
+    if (valid) {
+      r = a.row_ids ? int64_t(a.row_ids[t]) : t;
+      u = a.users[r];
+      i = a.items[r];
+    }
+    double dot = 0.0;
+    if (valid) {
+      const double* pu = a.P + int64_t(u) * k;
+      const double* qi = a.Q + int64_t(i) * k;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int f = (c * LPR + l) * VEC;
+        if (f < k) {
+          MfPack<VEC> pp, pq;
+          pp.load(pu + f);
+          pq.load(qi + f);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) dot += pp.v[v] * pq.v[v];
+        }
+      }
+    }
+    dot = mf_group_sum<LPR>(dot);
+    if (valid && l == 0) {
+      const double pred = mf_sigmoid(dot + a.bu[u] + a.bi[i] + a.b);
+      if (a.out_pred) a.out_pred[t] = pred;
+      if (a.loss_partial) {
+        const double rr = a.y[r] / a.pscore[r];
+        loss_acc += rr * log(pred + a.eps) + (1.0 - rr) * log(1.0 - pred + a.eps);
+      }
+    }
+  }
+  if (a.loss_partial) {
+    lds[tid] = loss_acc;
+    __syncthreads();
+#pragma unroll
+    for (int s = kMfBlock / 2; s > 0; s >>= 1) {
+      if (tid < s) lds[tid] += lds[tid + s];
+      __syncthreads();
+    }
+    if (tid == 0) a.loss_partial[blockIdx.x] = lds[0];
+  }
+}
+
+__global__ __launch_bounds__(kMfBlock) void mf_loss_finish_kernel(const double* partial,
+                                                                 int n_partial, int64_t n_rows,
+                                                                 double* out) {
+  __shared__ double lds[kMfBlock];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_partial; i += kMfBlock) acc += partial[i];
+  lds[threadIdx.x] = acc;
+  __syncthreads();
+#pragma unroll
+  for (int s = kMfBlock / 2; s > 0; s >>= 1) {
+    if (int(threadIdx.x) < s) lds[threadIdx.x] += lds[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = -lds[0] / double(n_rows);
+}
+
+struct MfSgdArgs {
+  const int32_t* users;
+  const int32_t* items;
+  const double* y;
+  const double* pscore;
+  const int32_t* pos_rows;   // batch position -> training row
+  const int32_t* order;      // batch positions grouped by level
+  const int32_t* level_ptr;  // device copy (sequential kernel only)
+  int32_t lo, hi;            // wide kernel: order[lo, hi); seq kernel: levels [lo, hi)
+  double* P;
+  double* Q;
+  double* bu;
+  double* bi;
+  double b;
+  int32_t k;
+  double lr, reg;
+};
+
+// one example, LPR lanes: src/mf.py:99-108 with :172-216
+template <int LPR, int VEC, int NC>
+__device__ inline void mf_example(const MfSgdArgs& a, int32_t s, int l) {
+  const int k = a.k;
+  const int64_t r = a.pos_rows[s];
+  const int32_t u = a.users[r], i = a.items[r];
+  double* pu = a.P + int64_t(u) * k;
+  double* qi = a.Q + int64_t(i) * k;
+  MfPack<VEC> pp[NC], pq[NC];
+  double dot = 0.0;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int f = (c * LPR + l) * VEC;
+    if (f < k) {
+      pp[c].load(pu + f);
+      pq[c].load(qi + f);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) dot += pp[c].v[v] * pq[c].v[v];
+    }
+  }
+  dot = mf_group_sum<LPR>(dot);
+  const double bu = a.bu[u], bi = a.bi[i];
+  const double err = a.y[r] / a.pscore[r] - mf_sigmoid(dot + bu + bi + a.b);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int f = (c * LPR + l) * VEC;
+    if (f < k) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const double p_new = pp[c].v[v] - a.lr * (-err * pq[c].v[v] + a.reg * pp[c].v[v]);
+        // the item row sees the user row this example has just updated (src/mf.py:193)
+        const double q_new = pq[c].v[v] - a.lr * (-err * p_new + a.reg * pq[c].v[v]);
+        pp[c].v[v] = p_new;
+        pq[c].v[v] = q_new;
+      }
+      pp[c].store(pu + f);
+      pq[c].store(qi + f);
+    }
+  }
+  if (l == 0) {
+    a.bu[u] = bu - a.lr * (-err + a.reg * bu);
+    a.bi[i] = bi - a.lr * (-err + a.reg * bi);
+  }
+}
+
+// one level, many workgroups
+template <int LPR, int VEC, int NC>
+__global__ __launch_bounds__(kMfBlock) void mf_sgd_wide_kernel(MfSgdArgs a) {
+  constexpr int GPB = kMfBlock / LPR;
+  const int l = threadIdx.x % LPR;
+  const int g = threadIdx.x / LPR;
+  for (int64_t idx = int64_t(a.lo) + int64_t(blockIdx.x) * GPB + g; idx < a.hi;
+       idx += int64_t(gridDim.x) * GPB)
+    mf_example<LPR, VEC, NC>(a, a.order[idx], l);
+}
+
+// levels [lo, hi) by one workgroup, barrier between levels
+template <int LPR, int VEC, int NC>
+__global__ __launch_bounds__(kSeqBlock) void mf_sgd_seq_kernel(MfSgdArgs a) {
+  constexpr int GPB = kSeqBlock / LPR;
+  const int l = threadIdx.x % LPR;
+  const int g = threadIdx.x / LPR;
+  for (int lev = a.lo; lev < a.hi; ++lev) {
+    const int32_t b0 = a.level_ptr[lev], b1 = a.level_ptr[lev + 1];
+    for (int32_t idx = b0 + g; idx < b1; idx += GPB) mf_example<LPR, VEC, NC>(a, a.order[idx], l);
+    __syncthreads();
+  }
+}
+
+struct MfShape {
+  int lpr, vec, nc;
+};
+
+inline MfShape mf_shape_for(int k) {
+  RFM_REQUIRE(k >= 1 && k <= RFM_MAX_FACTORS, "n_factors=%d unsupported (1..%d)", k,
+              RFM_MAX_FACTORS);
+  MfShape s;
+  s.vec = (k % 2 == 0) ? 2 : 1;
+  const int units = (k + s.vec - 1) / s.vec;
+  int lpr = 4;
+  while (lpr < units && lpr < 64) lpr *= 2;
+  s.lpr = lpr;
+  int nc = 1;
+  while (lpr * nc < units) nc *= 2;
+  s.nc = nc;
+  return s;
+}
+
+#define RFM_MF_FOR_SHAPE(S, CALL)                                                      \
+  do {                                                                                 \
+    const ::rfm::MfShape _s = (S);                                                     \
+    if (_s.vec == 2) {                                                                 \
+      if (_s.nc == 1) {                                                                \
+        switch (_s.lpr) {                                                              \
+          case 4: CALL(4, 2, 1); break;                                                \
+          case 8: CALL(8, 2, 1); break;                                                \
+          case 16: CALL(16, 2, 1); break;                                              \
+          case 32: CALL(32, 2, 1); break;                                              \
+          default: CALL(64, 2, 1); break;                                              \
+        }                                                                              \
+      } else if (_s.nc == 2) { CALL(64, 2, 2); }                                       \
+      else if (_s.nc == 4) { CALL(64, 2, 4); }                                         \
+      else { CALL(64, 2, 8); }                                                         \
+    } else {                                                                           \
+      if (_s.nc == 1) {                                                                \
+        switch (_s.lpr) {                                                              \
+          case 4: CALL(4, 1, 1); break;                                                \
+          case 8: CALL(8, 1, 1); break;                                                \
+          case 16: CALL(16, 1, 1); break;                                              \
+          case 32: CALL(32, 1, 1); break;                                              \
+          default: CALL(64, 1, 1); break;                                              \
+        }                                                                              \
+      } else if (_s.nc == 2) { CALL(64, 1, 2); }                                       \
+      else if (_s.nc == 4) { CALL(64, 1, 4); }                                         \
+      else if (_s.nc == 8) { CALL(64, 1, 8); }                                         \
+      else { CALL(64, 1, 16); }                                                        \
+    }                                                                                  \
+  } while (0)
+
+static void mf_predict_launch(rfm_ctx* ctx, MfPredArgs a, double* d_out_loss) {
+  if (a.n_rows <= 0) return;
+  const MfShape s = mf_shape_for(a.k);
+  const int gpb = kMfBlock / s.lpr;
+  const int grid = int(std::max<int64_t>(
+      1, std::min<int64_t>((a.n_rows + gpb - 1) / gpb, int64_t(ctx->n_cu) * 8)));
+  if (d_out_loss) {
+    ctx->loss_partials.ensure(size_t(ctx->n_cu) * 8 * sizeof(double));
+    a.loss_partial = ctx->loss_partials.as<double>();
+  }
+#define RFM_CALL_MFP(L, Vv, N) \
+  hipLaunchKernelGGL((mf_predict_kernel<L, Vv, N>), dim3(grid), dim3(kMfBlock), 0, ctx->stream, a)
+  RFM_MF_FOR_SHAPE(s, RFM_CALL_MFP);
+#undef RFM_CALL_MFP
+  if (d_out_loss)
+    hipLaunchKernelGGL(mf_loss_finish_kernel, dim3(1), dim3(kMfBlock), 0, ctx->stream,
+                       ctx->loss_partials.as<double>(), grid, a.n_rows, d_out_loss);
+  RFM_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace rfm
+
+using namespace rfm;
+
+extern "C" {
+
+int32_t rfm_mf_predict(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d_items,
+                       const int32_t* d_row_ids, int64_t n_rows, const double* d_P,
+                       const double* d_Q, const double* d_bu, const double* d_bi, double b,
+                       int32_t n_factors, double* d_out_pred) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx, "null ctx");
+    RFM_REQUIRE(n_rows >= 0, "negative n_rows");
+    if (n_rows == 0) return;
+    RFM_REQUIRE(d_P && d_Q && d_bu && d_bi && d_out_pred, "null pointer");
+    RFM_REQUIRE(d_users && d_items, "null pair arrays");
+    MfPredArgs a{};
+    a.users = d_users;
+    a.items = d_items;
+    a.row_ids = d_row_ids;
+    a.n_rows = n_rows;
+    a.P = d_P;
+    a.Q = d_Q;
+    a.bu = d_bu;
+    a.bi = d_bi;
+    a.b = b;
+    a.k = n_factors;
+    a.out_pred = d_out_pred;
+    mf_predict_launch(ctx, a, nullptr);
+  });
+}
+
+int32_t rfm_mf_predict_loss(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d_items,
+                            const double* d_y, const double* d_pscore,
+                            const int32_t* d_row_ids, int64_t n_rows, const double* d_P,
+                            const double* d_Q, const double* d_bu, const double* d_bi,
+                            double b, int32_t n_factors, double eps, double* d_out_pred,
+                            double* d_out_loss) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx && d_users && d_items && d_y && d_pscore && d_P && d_Q && d_bu && d_bi &&
+                    d_out_loss,
+                "null pointer");
+    RFM_REQUIRE(n_rows >= 1, "loss of zero rows");
+    MfPredArgs a{};
+    a.users = d_users;
+    a.items = d_items;
+    a.row_ids = d_row_ids;
+    a.n_rows = n_rows;
+    a.P = d_P;
+    a.Q = d_Q;
+    a.bu = d_bu;
+    a.bi = d_bi;
+    a.b = b;
+    a.k = n_factors;
+    a.y = d_y;
+    a.pscore = d_pscore;
+    a.eps = eps;
+    a.out_pred = d_out_pred;
+    mf_predict_launch(ctx, a, d_out_loss);
+  });
+}
+
+int32_t rfm_mf_sgd_levels(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d_items,
+                          const double* d_y, const double* d_pscore,
+                          const int32_t* d_pos_rows, const int32_t* d_order,
+                          const int32_t* h_level_ptr, const int32_t* d_level_ptr,
+                          int32_t n_levels, double* d_P, double* d_Q, double* d_bu,
+                          double* d_bi, double b, int32_t n_factors, double lr, double reg) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx && d_users && d_items && d_y && d_pscore && d_pos_rows && d_order &&
+                    h_level_ptr && d_level_ptr && d_P && d_Q && d_bu && d_bi,
+                "null pointer");
+    RFM_REQUIRE(n_levels >= 0, "negative n_levels");
+    const MfShape s = mf_shape_for(n_factors);
+    MfSgdArgs a{};
+    a.users = d_users;
+    a.items = d_items;
+    a.y = d_y;
+    a.pscore = d_pscore;
+    a.pos_rows = d_pos_rows;
+    a.order = d_order;
+    a.level_ptr = d_level_ptr;
+    a.P = d_P;
+    a.Q = d_Q;
+    a.bu = d_bu;
+    a.bi = d_bi;
+    a.b = b;
+    a.k = n_factors;
+    a.lr = lr;
+    a.reg = reg;
+    // a level is "small" when one pass of the sequential workgroup covers it
+    const int seq_cap = 2 * (kSeqBlock / s.lpr);
+    int lev = 0;
+    while (lev < n_levels) {
+      const int cnt = h_level_ptr[lev + 1] - h_level_ptr[lev];
+      RFM_REQUIRE(cnt >= 0, "level_ptr not monotone");
+      if (cnt > seq_cap) {
+        a.lo = h_level_ptr[lev];
+        a.hi = h_level_ptr[lev + 1];
+        const int gpb = kMfBlock / s.lpr;
+        const int grid = std::min((cnt + gpb - 1) / gpb, ctx->n_cu * 8);
+#define RFM_CALL_WIDE(L, Vv, N)                                                               \
+  hipLaunchKernelGGL((mf_sgd_wide_kernel<L, Vv, N>), dim3(grid), dim3(kMfBlock), 0, ctx->stream, \
+                     a)
+        RFM_MF_FOR_SHAPE(s, RFM_CALL_WIDE);
+#undef RFM_CALL_WIDE
+        ++lev;
+      } else {
+        int end = lev;
+        while (end < n_levels && h_level_ptr[end + 1] - h_level_ptr[end] <= seq_cap) ++end;
+        a.lo = lev;
+        a.hi = end;
+#define RFM_CALL_SEQ(L, Vv, N) \
+  hipLaunchKernelGGL((mf_sgd_seq_kernel<L, Vv, N>), dim3(1), dim3(kSeqBlock), 0, ctx->stream, a)
+        RFM_MF_FOR_SHAPE(s, RFM_CALL_SEQ);
+#undef RFM_CALL_SEQ
+        lev = end;
+      }
+    }
+    RFM_HIP_CHECK(hipGetLastError());
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,154 @@
+"""``FactorizationMachines`` with the reference's surface (``src/fm.py:17-133``)
+on top of the HIP kernels of librfm_hip.so.
+
+Same dataclass fields, same ``fit(train, val) -> (train_loss, val_loss)`` and
+``predict(X)`` / ``predict(X=...)``, same side attributes (``val_metrics``,
+``model_name`` when an evaluator is given; ``w0``, ``w``, ``V`` callables).  The
+host only prepares inputs (parameter init with the reference's NumPy calls,
+mini-batch ids, uploads) and enqueues; every floating-point operation of the
+loop runs in the kernels of ``csrc/rfm_fm.hip``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from .base import LOSS_EPS, PointwiseBaseRecommender
+from .optimizer import DeviceSGD
+from .runtime import CsrCache, DeviceCSR, Runtime, sample_batches
+
+
+class FmPlan:
+    """Owner of an ``rfm_fm_plan`` (column-major view of a training CSR)."""
+
+    def __init__(self, rt: Runtime, csr: DeviceCSR, n_factors: int, max_batch: int,
+                 hot_min_count: int = 0):
+        self.rt = rt
+        handle = C.c_void_p()
+        _lib.check(rt.lib.rfm_fm_plan_create(
+            rt.ctx, csr.h_indptr.ctypes.data, csr.h_indices.ctypes.data, csr.h_values.ctypes.data,
+            csr.shape[0], csr.shape[1], n_factors, max_batch, hot_min_count, C.byref(handle)))
+        self.handle = handle
+
+    def info(self) -> dict:
+        out = np.zeros(5, dtype=np.int64)
+        _lib.check(self.rt.lib.rfm_fm_plan_info(self.handle, out.ctypes.data))
+        return dict(zip(("work_items", "split_columns", "hot_columns", "nnz", "device_bytes"),
+                        (int(v) for v in out)))
+
+    def close(self) -> None:
+        if self.handle is not None:
+            self.rt.lib.rfm_fm_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class FactorizationMachines(PointwiseBaseRecommender):
+    """Factorization Machines trained by mini-batch SGD on an MI355X.
+
+    Args (``src/fm.py:20-29``):
+    - n_features (int): number of feature columns
+    - alpha (float): scale of the uniform initialisation
+    - evaluator: optional object with ``.features["FM"]`` and
+      ``.evaluate(y_scores=, estimator=)`` (the reference's ``ValEvaluator``)
+    """
+
+    n_features: int
+    alpha: float = 2.0
+    evaluator: Optional[object] = None
+
+    def __post_init__(self) -> None:
+        # src/fm.py:31-53 -- the reference's NumPy calls, in its draw order
+        np.random.seed(self.seed)
+        w0 = np.array([0.0])
+        limit = self.alpha * np.sqrt(6 / self.n_features)
+        w = np.random.uniform(low=-limit, high=limit, size=self.n_features)
+        limit = self.alpha * np.sqrt(6 / self.n_factors)
+        V = np.random.uniform(low=-limit, high=limit, size=(self.n_features, self.n_factors))
+
+        self._rt = Runtime.get()
+        self.w0 = DeviceSGD(self._rt, w0, self.lr)
+        self.w = DeviceSGD(self._rt, w, self.lr)
+        self.V = DeviceSGD(self._rt, V, self.lr)
+        self._csr_cache = CsrCache(self._rt)
+
+        if self.evaluator is not None:
+            self.val_metrics = []
+            self.model_name = "FM"
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, train: dict, val: dict) -> tuple:
+        """src/fm.py:55-112.  One "epoch" is one mini-batch step; returns the
+        per-iteration train and validation IPS log-loss as two lists."""
+        rt = self._rt
+        X = train["features"]
+        n_rows = X.shape[0]
+        if X.shape[1] != self.n_features:
+            raise ValueError(f"train features have {X.shape[1]} columns, model has {self.n_features}")
+        if self.n_epochs <= 0:
+            return [], []
+        # batch selection: resample(..., random_state=epoch) (src/fm.py:72-79)
+        ids = sample_batches(n_rows, self.batch_size, 0, self.n_epochs)
+
+        tr = DeviceCSR(rt, X)
+        y = rt.upload(np.asarray(train["labels"]), dtype=np.float64)
+        p = rt.upload(np.asarray(train["pscores"]), dtype=np.float64)
+        va = DeviceCSR(rt, val["features"])
+        vy = rt.upload(np.asarray(val["labels"]), dtype=np.float64)
+        vp = rt.upload(np.asarray(val["pscores"]), dtype=np.float64)
+        d_ids = rt.upload(ids)
+        plan = FmPlan(rt, tr, self.n_factors, self.batch_size)
+        tl = rt.empty((self.n_epochs,), y.dtype)
+        vl = rt.empty((self.n_epochs,), y.dtype)
+
+        def run(first: int, count: int) -> None:
+            _lib.check(rt.lib.rfm_fm_train(
+                rt.ctx, plan.handle, tr.indptr.data_ptr(), tr.indices.data_ptr(), tr.values.data_ptr(),
+                y.data_ptr(), p.data_ptr(), d_ids.data_ptr() + first * self.batch_size * 4,
+                self.batch_size, count,
+                self.w0.dev.data_ptr(), self.w.dev.data_ptr(), self.V.dev.data_ptr(), float(self.lr),
+                va.indptr.data_ptr(), va.indices.data_ptr(), va.values.data_ptr(),
+                vy.data_ptr(), vp.data_ptr(), va.shape[0], LOSS_EPS,
+                tl.data_ptr() + first * 8, vl.data_ptr() + first * 8))
+
+        try:
+            if self.evaluator is None:
+                run(0, self.n_epochs)
+            else:
+                # the evaluator is a host callback: one iteration per enqueue
+                for epoch in range(self.n_epochs):
+                    run(epoch, 1)
+                    y_scores = self.predict(X=self.evaluator.features[self.model_name])
+                    self.val_metrics.append(
+                        self.evaluator.evaluate(y_scores=y_scores, estimator=self.estimator))
+            rt.sync()
+        finally:
+            rt.sync()
+            plan.close()
+        return tl.cpu().numpy().tolist(), vl.cpu().numpy().tolist()
+
+    # -------------------------------------------------------------- predict
+    def predict(self, X) -> np.ndarray:
+        """src/fm.py:114-133 -- scores of the rows of a sparse matrix."""
+        rt = self._rt
+        if X.shape[1] != self.n_features:
+            raise ValueError(f"X has {X.shape[1]} columns, model has {self.n_features}")
+        dev = self._csr_cache.get(X)
+        n = dev.shape[0]
+        out = rt.empty((n,), self.w.dev.dtype)
+        _lib.check(rt.lib.rfm_fm_forward(
+            rt.ctx, dev.indptr.data_ptr(), dev.indices.data_ptr(), dev.values.data_ptr(), None, n,
+            self.w0.dev.data_ptr(), self.w.dev.data_ptr(), self.V.dev.data_ptr(),
+            self.n_features, self.n_factors, out.data_ptr()))
+        rt.sync()
+        return out.cpu().numpy()

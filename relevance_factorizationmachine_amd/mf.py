@@ -1,0 +1,149 @@
+"""``LogisticMatrixFactorization`` with the reference's surface
+(``src/mf.py:16-170``) on top of the HIP kernels of librfm_hip.so.
+
+The reference updates a batch strictly example by example
+(``src/mf.py:97-108``).  That order is kept exactly: the host derives, per
+batch, the level schedule (``rfm_mf_schedule``) under which every example runs
+after the latest earlier example sharing its user or item, and the device
+executes the levels in order (``csrc/rfm_mf.hip``).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from .base import LOSS_EPS, PointwiseBaseRecommender
+from .optimizer import DeviceSGD
+from .runtime import Runtime, mf_schedule, sample_batches
+
+
+class DevicePairs:
+    """(user, item) pairs of a log in HBM as two int32 arrays."""
+
+    def __init__(self, rt: Runtime, pairs: np.ndarray):
+        pairs = np.asarray(pairs)
+        if pairs.ndim != 2 or pairs.shape[1] < 2:
+            raise ValueError("MF features must be an (N, 2) array of [user, item]")
+        self.n = int(pairs.shape[0])
+        self.h_users = np.ascontiguousarray(pairs[:, 0], dtype=np.int32)
+        self.h_items = np.ascontiguousarray(pairs[:, 1], dtype=np.int32)
+        self.users = rt.upload(self.h_users if self.n else np.zeros(1, np.int32))
+        self.items = rt.upload(self.h_items if self.n else np.zeros(1, np.int32))
+
+
+@dataclass
+class LogisticMatrixFactorization(PointwiseBaseRecommender):
+    """Logistic matrix factorisation trained by per-example SGD on an MI355X.
+
+    Args (``src/mf.py:20-32``): n_users, n_items, reg (L2 on touched rows),
+    alpha (init scale), evaluator (optional ``ValEvaluator``-like object).
+    """
+
+    n_users: int
+    n_items: int
+    reg: float
+    alpha: float = 4.0
+    evaluator: Optional[object] = None
+
+    def __post_init__(self) -> None:
+        # src/mf.py:34-66 -- the reference's NumPy calls, in its draw order
+        np.random.seed(self.seed)
+        limit = self.alpha * np.sqrt(6 / self.n_factors)
+        P = np.random.uniform(low=-limit, high=limit, size=(self.n_users, self.n_factors))
+        Q = np.random.uniform(low=-limit, high=limit, size=(self.n_items, self.n_factors))
+        b_u = np.random.normal(scale=0.001, size=self.n_users)
+        b_i = np.random.normal(scale=0.001, size=self.n_items)
+
+        self._rt = Runtime.get()
+        self.P = DeviceSGD(self._rt, P, self.lr)
+        self.Q = DeviceSGD(self._rt, Q, self.lr)
+        self.b_u = DeviceSGD(self._rt, b_u, self.lr)
+        self.b_i = DeviceSGD(self._rt, b_i, self.lr)
+
+        if self.evaluator is not None:
+            self.val_metrics = []
+            self.model_name = "MF"
+
+    def _check_ids(self, pairs: DevicePairs) -> None:
+        if pairs.n == 0:
+            return
+        if pairs.h_users.min() < 0 or pairs.h_users.max() >= self.n_users:
+            raise IndexError("user id out of range")
+        if pairs.h_items.min() < 0 or pairs.h_items.max() >= self.n_items:
+            raise IndexError("item id out of range")
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, train: dict, val: dict) -> tuple:
+        """src/mf.py:68-134."""
+        rt = self._rt
+        # global bias: mean of the training labels (src/mf.py:84)
+        self.b = np.mean(train["labels"])
+        n_rows = int(np.asarray(train["features"]).shape[0])
+        if self.n_epochs <= 0:
+            return [], []
+        ids = sample_batches(n_rows, self.batch_size, 0, self.n_epochs)
+
+        tr = DevicePairs(rt, train["features"])
+        va = DevicePairs(rt, val["features"])
+        self._check_ids(tr)
+        self._check_ids(va)
+        y = rt.upload(np.asarray(train["labels"]), dtype=np.float64)
+        p = rt.upload(np.asarray(train["pscores"]), dtype=np.float64)
+        vy = rt.upload(np.asarray(val["labels"]), dtype=np.float64)
+        vp = rt.upload(np.asarray(val["pscores"]), dtype=np.float64)
+        d_ids = rt.upload(ids)
+        tl = rt.empty((self.n_epochs,), y.dtype)
+        vl = rt.empty((self.n_epochs,), y.dtype)
+        params = (self.P.dev.data_ptr(), self.Q.dev.data_ptr(), self.b_u.dev.data_ptr(),
+                  self.b_i.dev.data_ptr())
+        b = float(self.b)
+        keep = []  # device buffers of in-flight iterations
+
+        for epoch in range(self.n_epochs):
+            rows = ids[epoch]
+            order, level_ptr = mf_schedule(tr.h_users[rows], tr.h_items[rows], self.n_users,
+                                           self.n_items)
+            d_order, d_lptr = rt.upload(order), rt.upload(level_ptr)
+            keep.append((d_order, d_lptr))
+            ids_ptr = d_ids.data_ptr() + epoch * self.batch_size * 4
+            _lib.check(rt.lib.rfm_mf_sgd_levels(
+                rt.ctx, tr.users.data_ptr(), tr.items.data_ptr(), y.data_ptr(), p.data_ptr(),
+                ids_ptr, d_order.data_ptr(), level_ptr.ctypes.data, d_lptr.data_ptr(),
+                len(level_ptr) - 1, *params, b, self.n_factors, float(self.lr), float(self.reg)))
+            # train loss on the same batch with the updated parameters (src/mf.py:110-116)
+            _lib.check(rt.lib.rfm_mf_predict_loss(
+                rt.ctx, tr.users.data_ptr(), tr.items.data_ptr(), y.data_ptr(), p.data_ptr(),
+                ids_ptr, self.batch_size, *params, b, self.n_factors, LOSS_EPS, None,
+                tl.data_ptr() + epoch * 8))
+            _lib.check(rt.lib.rfm_mf_predict_loss(
+                rt.ctx, va.users.data_ptr(), va.items.data_ptr(), vy.data_ptr(), vp.data_ptr(),
+                None, va.n, *params, b, self.n_factors, LOSS_EPS, None, vl.data_ptr() + epoch * 8))
+            if self.evaluator is not None:
+                y_scores = self.predict(self.evaluator.features[self.model_name])
+                self.val_metrics.append(
+                    self.evaluator.evaluate(y_scores=y_scores, estimator=self.estimator))
+            if len(keep) > 64:
+                rt.sync()
+                keep.clear()
+        rt.sync()
+        return tl.cpu().numpy().tolist(), vl.cpu().numpy().tolist()
+
+    # -------------------------------------------------------------- predict
+    def predict(self, X) -> np.ndarray:
+        """src/mf.py:136-152 -- scores of (user, item) pairs."""
+        rt = self._rt
+        if not hasattr(self, "b"):
+            # the reference's global bias exists only after fit() (src/mf.py:84)
+            raise AttributeError("'LogisticMatrixFactorization' object has no attribute 'b'")
+        pairs = DevicePairs(rt, X)
+        self._check_ids(pairs)
+        out = rt.empty((pairs.n,), self.P.dev.dtype)
+        _lib.check(rt.lib.rfm_mf_predict(
+            rt.ctx, pairs.users.data_ptr(), pairs.items.data_ptr(), None, pairs.n,
+            self.P.dev.data_ptr(), self.Q.dev.data_ptr(), self.b_u.dev.data_ptr(),
+            self.b_i.dev.data_ptr(), float(self.b), self.n_factors, out.data_ptr()))
+        rt.sync()
+        return out.cpu().numpy()

@@ -1,0 +1,145 @@
+"""Device plumbing: a per-device context of librfm_hip.so, torch tensors as the
+device containers, and the host-side helpers (sampler, MF schedule) that need
+no GPU.  PyTorch is used for allocation, copies and streams only -- no torch
+operator runs on the training path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import weakref
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def ptr(t) -> Optional[int]:
+    """Device (or host) address of a torch tensor / numpy array, or None."""
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        return t.ctypes.data
+    return t.data_ptr()
+
+
+class Runtime:
+    """One librfm context on one GPU, bound to torch's current stream."""
+
+    _instances: Dict[int, "Runtime"] = {}
+
+    def __init__(self, device: int):
+        torch = _torch()
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.RfmError(
+                "no GPU visible: relevance_factorizationmachine_amd runs its training path only "
+                "as HIP kernels on an MI355X (there is no CPU fallback)")
+        self.device = device
+        self.torch_device = torch.device("cuda", device)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream().cuda_stream
+        handle = C.c_void_p()
+        _lib.check(self.lib.rfm_create(device, C.c_void_p(stream), C.byref(handle)))
+        self.ctx = handle
+        weakref.finalize(self, self.lib.rfm_destroy, handle)
+
+    @classmethod
+    def get(cls, device: Optional[int] = None) -> "Runtime":
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) if _torch().cuda.device_count() > 1 else 0
+        rt = cls._instances.get(device)
+        if rt is None:
+            rt = cls(device)
+            cls._instances[device] = rt
+        return rt
+
+    # ---- containers -------------------------------------------------------
+    def upload(self, a: np.ndarray, dtype=None):
+        torch = _torch()
+        arr = np.ascontiguousarray(a if dtype is None else np.asarray(a, dtype=dtype))
+        return torch.from_numpy(arr).to(self.torch_device)
+
+    def empty(self, shape, dtype):
+        torch = _torch()
+        return torch.empty(shape, dtype=dtype, device=self.torch_device)
+
+    def sync(self) -> None:
+        _lib.check(self.lib.rfm_sync(self.ctx))
+
+
+class DeviceCSR:
+    """CSR matrix resident in HBM: indptr int64, indices int32, values f64."""
+
+    def __init__(self, rt: Runtime, X):
+        from scipy import sparse
+
+        X = X.tocsr() if not sparse.isspmatrix_csr(X) else X
+        self.shape: Tuple[int, int] = X.shape
+        self.nnz = int(X.nnz)
+        # host copies in the ABI's dtypes (kept for the plan builder)
+        self.h_indptr = np.ascontiguousarray(X.indptr, dtype=np.int64)
+        self.h_indices = np.ascontiguousarray(X.indices, dtype=np.int32)
+        self.h_values = np.ascontiguousarray(X.data, dtype=np.float64)
+        self.indptr = rt.upload(self.h_indptr)
+        self.indices = rt.upload(self.h_indices if self.nnz else np.zeros(1, np.int32))
+        self.values = rt.upload(self.h_values if self.nnz else np.zeros(1, np.float64))
+
+
+class CsrCache:
+    """Remembers the device copy of the last few host matrices handed to
+    predict() (the evaluator hook passes the same object every iteration)."""
+
+    def __init__(self, rt: Runtime, capacity: int = 4):
+        self.rt = rt
+        self.capacity = capacity
+        self._items = []  # (weakref, key, DeviceCSR)
+
+    def get(self, X) -> DeviceCSR:
+        key = (id(X), X.shape, int(X.nnz))
+        for ref, k, dev in self._items:
+            if k == key and ref() is X:
+                return dev
+        dev = DeviceCSR(self.rt, X)
+        try:
+            self._items.append((weakref.ref(X), key, dev))
+        except TypeError:
+            return dev
+        if len(self._items) > self.capacity:
+            self._items.pop(0)
+        return dev
+
+
+# ---- host-only helpers (no GPU needed) -------------------------------------
+def sample_batches(n_rows: int, batch_size: int, epoch_begin: int, n_epochs: int,
+                   n_threads: int = 0) -> np.ndarray:
+    """Row ids of iterations ``epoch_begin .. +n_epochs`` as ``(n_epochs, B)``
+    int32 -- what ``resample(..., random_state=epoch)`` selects
+    (src/fm.py:72-79).  Raises ValueError if ``batch_size > n_rows``."""
+    lib = _lib.load()
+    out = np.empty((max(n_epochs, 0), batch_size), dtype=np.int32)
+    if n_threads <= 0:
+        n_threads = min(os.cpu_count() or 1, 32)
+    _lib.check(lib.rfm_sample_batches(n_rows, batch_size, epoch_begin, n_epochs,
+                                      out.ctypes.data, n_threads))
+    return out
+
+
+def mf_schedule(users: np.ndarray, items: np.ndarray, n_users: int, n_items: int):
+    """Level schedule of one batch: ``(order int32[B], level_ptr int32[L+1])``."""
+    lib = _lib.load()
+    users = np.ascontiguousarray(users, dtype=np.int32)
+    items = np.ascontiguousarray(items, dtype=np.int32)
+    b = users.shape[0]
+    order = np.empty(b, dtype=np.int32)
+    level_ptr = np.empty(b + 1, dtype=np.int32)
+    n_levels = C.c_int32(0)
+    _lib.check(lib.rfm_mf_schedule(users.ctypes.data, items.ctypes.data, b, n_users, n_items,
+                                   order.ctypes.data, level_ptr.ctypes.data, C.byref(n_levels)))
+    return order, level_ptr[: n_levels.value + 1].copy()

@@ -1,0 +1,327 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the
+golden vectors the reference produced.  Needs an MI355X: ``pytest -m gpu``.
+
+Tolerance: BASELINE.json asks for <= 1e-5 relative on learned parameters and
+scores.  Everything is float64 on both sides and differs only in summation
+order, so the tests hold the path to CONTRACT/1e4 = 1e-9 to catch regressions
+early; ``rel_err`` is max|a-b| / max|b|.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+from scipy.sparse import csr_matrix, random as sprandom
+
+from conftest import load_golden, rel_err
+from oracle import cpu_ref
+from relevance_factorizationmachine_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CONTRACT = 1e-5
+TIGHT = 1e-9
+
+
+@pytest.fixture(scope="module")
+def rfm():
+    import relevance_factorizationmachine_amd as pkg
+    from relevance_factorizationmachine_amd import _lib, runtime
+    rt = runtime.Runtime.get()
+    return pkg, _lib, runtime, rt
+
+
+def _fm(pkg, **kw):
+    base = dict(estimator="IPS", n_epochs=1, n_factors=8, lr=1e-3, batch_size=1, seed=12345)
+    base.update(kw)
+    return pkg.FactorizationMachines(**base)
+
+
+# --------------------------------------------------------------------------
+# golden end-to-end fits (configs 1 and 2 of BASELINE.json)
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("est", ["IPS", "Naive"])
+@pytest.mark.parametrize("fixture,shape", [("fm_coat_k8", "coat"), ("fm_kuairec_small_k16", "kuairec_small")])
+def test_fm_fit_matches_reference_golden(rfm, fixture, shape, est):
+    pkg = rfm[0]
+    g = load_golden(fixture)
+    sh = synth.SHAPES[shape]
+    train, val = synth.make_log(sh, "FM", est, seed=0)
+    model = pkg.FactorizationMachines(
+        estimator=est, n_epochs=int(g["n_epochs"]), n_factors=sh.n_factors,
+        n_features=train["features"].shape[1], lr=float(g[f"{est}_lr"]),
+        batch_size=sh.batch_size, seed=int(g["seed"]))
+    tr, va = model.fit(train, val)
+    assert isinstance(tr, list) and isinstance(va, list) and len(tr) == len(va) == int(g["n_epochs"])
+    assert rel_err(model.V(), g[f"{est}_V"]) < TIGHT
+    assert rel_err(model.w(), g[f"{est}_w"]) < TIGHT
+    assert rel_err(model.w0(), g[f"{est}_w0"]) < TIGHT
+    assert abs(model.w0(0) - g[f"{est}_w0"][0]) <= TIGHT * max(1.0, abs(g[f"{est}_w0"][0]))
+    assert rel_err(tr, g[f"{est}_train_loss"]) < TIGHT
+    assert rel_err(va, g[f"{est}_val_loss"]) < TIGHT
+    pred = model.predict(X=val["features"])
+    assert pred.dtype == np.float64 and pred.ndim == 1
+    assert rel_err(pred, g[f"{est}_pred_val"]) < TIGHT
+    assert rel_err(pred, g[f"{est}_pred_val"]) < CONTRACT
+    np.testing.assert_array_equal(model.predict(val["features"]), pred)  # positional call too
+
+
+@pytest.mark.parametrize("est", ["IPS", "Naive"])
+def test_mf_fit_matches_reference_golden(rfm, est):
+    pkg = rfm[0]
+    g = load_golden("mf_small")
+    sh = synth.SHAPES["kuairec_small"]
+    train, val = synth.make_log(sh, "MF", est, seed=0)
+    model = pkg.LogisticMatrixFactorization(
+        estimator=est, n_epochs=3, n_factors=16, n_users=sh.n_users, n_items=sh.n_items,
+        lr=0.01, reg=0.5, batch_size=2000, seed=12345)
+    with pytest.raises(AttributeError):
+        model.predict(val["features"])  # the global bias exists only after fit (src/mf.py:84)
+    tr, va = model.fit(train, val)
+    for nm in ("P", "Q", "b_u", "b_i"):
+        assert rel_err(getattr(model, nm)(), g[f"{est}_{nm}"]) < TIGHT, nm
+    assert model.b == float(g[f"{est}_b"])
+    assert rel_err(tr, g[f"{est}_train_loss"]) < TIGHT
+    assert rel_err(va, g[f"{est}_val_loss"]) < TIGHT
+    assert rel_err(model.predict(val["features"]), g[f"{est}_pred_val"]) < TIGHT
+
+
+def test_dcg_parity_on_gpu_scores(rfm):
+    """DCG@5 of the GPU's validation scores equals the reference's (fixture G7)."""
+    pkg = rfm[0]
+    g, gd = load_golden("fm_kuairec_small_k16"), load_golden("val_dcg")
+    sh = synth.SHAPES["kuairec_small"]
+    for est in ("IPS", "Naive"):
+        train, val = synth.make_log(sh, "FM", est, seed=0)
+        _, val_mf = synth.make_log(sh, "MF", est, seed=0)
+        frame = synth.interaction_frame(val_mf, val_mf["features"])
+
+        class Hook:  # the ValEvaluator contract (utils/evaluate.py:160-207)
+            features = {"FM": val["features"]}
+
+            def evaluate(self, y_scores, estimator):
+                return cpu_ref.val_dcg(frame, y_scores, estimator, k=5)
+
+        model = pkg.FactorizationMachines(
+            estimator=est, n_epochs=int(g["n_epochs"]), n_factors=16, n_features=train["features"].shape[1],
+            lr=float(g[f"{est}_lr"]), batch_size=2000, seed=12345, evaluator=Hook())
+        assert model.model_name == "FM" and model.val_metrics == []
+        model.fit(train, val)
+        assert len(model.val_metrics) == int(g["n_epochs"])
+        assert model.val_metrics[-1] == pytest.approx(float(gd[f"g2_val_dcg_{est}"]), rel=1e-9)
+
+
+# --------------------------------------------------------------------------
+# known-answer step (fixture G3: k=3, odd factor count, non-unit values)
+# --------------------------------------------------------------------------
+def test_fm_one_step_known_answer(rfm):
+    pkg, _lib, runtime, rt = rfm
+    g = load_golden("fm_one_step_tiny")
+    X = csr_matrix(g["dense"])
+    train = {"features": X, "labels": g["y"], "pscores": g["p"]}
+    model = _fm(pkg, n_factors=3, n_features=5, lr=float(g["lr"]), batch_size=6, seed=int(g["seed"]))
+    np.testing.assert_array_equal(model.V(), g["V_init"])
+    np.testing.assert_array_equal(model.w(), g["w_init"])
+    # gradients through rfm_fm_grad
+    from relevance_factorizationmachine_amd.fm import FmPlan
+    dev = runtime.DeviceCSR(rt, X)
+    plan = FmPlan(rt, dev, 3, 6)
+    ids = rt.upload(cpu_ref.batch_ids(6, 6, 0).astype(np.int32))
+    y, p = rt.upload(g["y"], dtype=np.float64), rt.upload(g["p"], dtype=np.float64)
+    grad = rt.empty((5 * 3 + 5 + 1,), y.dtype)
+    _lib.check(rt.lib.rfm_fm_grad(rt.ctx, plan.handle, dev.indptr.data_ptr(), dev.indices.data_ptr(),
+                                  dev.values.data_ptr(), y.data_ptr(), p.data_ptr(), ids.data_ptr(), 6,
+                                  model.w0.dev.data_ptr(), model.w.dev.data_ptr(), model.V.dev.data_ptr(),
+                                  grad.data_ptr()))
+    rt.sync()
+    gh = grad.cpu().numpy()
+    assert rel_err(gh[:15].reshape(5, 3), g["G_V"]) < 1e-8  # fixture gradients are (before-after)/lr
+    assert rel_err(gh[15:20], g["g_w"]) < 1e-8
+    assert rel_err(gh[20], g["g_w0"]) < 1e-8
+    plan.close()
+    tr, va = model.fit(train, train)
+    assert rel_err(model.V(), g["V_after"]) < TIGHT
+    assert rel_err(model.w(), g["w_after"]) < TIGHT
+    assert rel_err(model.w0(), g["w0_after"]) < TIGHT
+    assert rel_err(tr, g["train_loss"]) < TIGHT and rel_err(va, g["val_loss"]) < TIGHT
+
+
+# --------------------------------------------------------------------------
+# edge cases: ragged / empty rows, odd and large k, full batch, untouched columns
+# --------------------------------------------------------------------------
+def _random_log(rng, n_rows, n_cols, density, dense_cols=0):
+    X = sprandom(n_rows, n_cols, density=density, format="csr", random_state=rng,
+                 data_rvs=lambda s: rng.standard_normal(s)).tolil()
+    for c in range(dense_cols):  # a few columns present in every row (long column lists)
+        X[:, c] = rng.standard_normal(n_rows)[:, None]
+    X = X.tocsr()
+    X.sort_indices()
+    y = (rng.random(n_rows) < 0.5).astype(np.int64)
+    p = rng.uniform(0.1, 1.0, size=n_rows) ** 0.5
+    return {"features": X, "labels": y, "pscores": p}
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 7, 8, 16, 30, 32, 33, 64, 100, 128, 129, 300, 400])
+def test_fm_forward_all_factor_counts(rfm, k):
+    pkg = rfm[0]
+    rng = np.random.default_rng(k)
+    log = _random_log(rng, 257, 90, 0.08)
+    log["features"][5, :] = 0  # an explicitly emptied row
+    log["features"].eliminate_zeros()
+    model = _fm(pkg, n_factors=k, n_features=90)
+    w0, w, V = cpu_ref.fm_init(12345, 90, k)
+    assert rel_err(model.predict(log["features"]), cpu_ref.fm_predict(log["features"], w0, w, V)) < TIGHT
+
+
+@pytest.mark.parametrize("k,batch,dense_cols", [(3, 64, 0), (8, 500, 2), (32, 6000, 3), (64, 999, 1), (300, 128, 1)])
+def test_fm_fit_ragged_logs(rfm, k, batch, dense_cols):
+    """Variable nnz per row, empty rows, columns nobody touches, column lists
+    longer than one chunk (dense columns x 6000 rows), batch == n_rows."""
+    pkg = rfm[0]
+    rng = np.random.default_rng(100 + k)
+    n_rows = max(batch, 6000 if batch == 6000 else 1500)
+    train = _random_log(rng, n_rows, 140, 0.05, dense_cols)
+    val = _random_log(rng, 333, 140, 0.05, dense_cols)
+    lr = 1e-4
+    model = _fm(pkg, n_factors=k, n_features=140, lr=lr, batch_size=batch, n_epochs=4, seed=3)
+    tr, va = model.fit(train, val)
+    ref = cpu_ref.fm_fit(train, val, n_epochs=4, n_factors=k, lr=lr, batch_size=batch, seed=3)
+    assert rel_err(model.V(), ref["V"]) < TIGHT
+    assert rel_err(model.w(), ref["w"]) < TIGHT
+    assert rel_err(model.w0(), ref["w0"]) < TIGHT
+    assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
+
+
+def test_saturated_logits_and_empty_inputs(rfm):
+    """_sigmoid clips at +-700 (fixture G9); rows without entries score sigmoid(w0)."""
+    pkg = rfm[0]
+    s = load_golden("sigmoid_edges")
+    model = _fm(pkg, n_factors=2, n_features=3)
+    empty_rows = csr_matrix((4, 3))
+    for x, want in zip(s["x"], s["y"]):
+        model.w0.set(np.array([x]))
+        got = model.predict(empty_rows)
+        assert got.shape == (4,)
+        assert np.all(np.abs(got - want) <= 1e-14 * want + 1e-320), (x, got[0], want)
+    assert model.predict(csr_matrix((0, 3))).shape == (0,)
+
+
+def test_logloss_cases(rfm):
+    pkg = rfm[0]
+    g = load_golden("logloss_cases")
+    model = _fm(pkg, n_factors=2, n_features=3)
+    assert model._cross_entropy_loss(g["y"], g["scores"], g["pscores"]) == pytest.approx(float(g["loss"]), rel=1e-13)
+    assert model._cross_entropy_loss(g["y"], g["scores"], np.ones(8)) == pytest.approx(float(g["loss_naive"]), rel=1e-13)
+    assert model._cross_entropy_loss(g["y"][:3], g["scores"][:3], g["pscores"][:3]) == pytest.approx(
+        float(g["loss_first3"]), rel=1e-13)
+
+
+def test_batch_larger_than_log_raises(rfm):
+    pkg = rfm[0]
+    train, val = synth.make_log("coat", "FM", "IPS", seed=0)
+    model = _fm(pkg, n_factors=8, n_features=train["features"].shape[1], batch_size=10 ** 6)
+    with pytest.raises(ValueError, match="Cannot sample"):
+        model.fit(train, val)
+
+
+@pytest.mark.parametrize("k,batch", [(1, 50), (5, 700), (16, 2000), (128, 512), (300, 64)])
+def test_mf_fit_vs_oracle(rfm, k, batch):
+    pkg = rfm[0]
+    rng = np.random.default_rng(k)
+    nu, ni, n = 300, 40, 3000
+    def log(m):
+        pairs = np.stack([rng.integers(0, nu, size=m), (rng.zipf(1.3, size=m) - 1) % ni], axis=1).astype(np.int64)
+        return {"features": pairs, "labels": (rng.random(m) < 0.5).astype(np.int64),
+                "pscores": rng.uniform(0.1, 1.0, size=m) ** 0.5}
+    train, val = log(n), log(500)
+    kw = dict(n_epochs=2, n_factors=k, lr=0.02, batch_size=batch, seed=9, n_users=nu, n_items=ni, reg=0.5)
+    model = pkg.LogisticMatrixFactorization(estimator="IPS", **kw)
+    tr, va = model.fit(train, val)
+    ref = cpu_ref.mf_fit(train, val, **kw)
+    for nm in ("P", "Q", "b_u", "b_i"):
+        assert rel_err(getattr(model, nm)(), ref[nm]) < TIGHT, nm
+    assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
+
+
+# --------------------------------------------------------------------------
+# full-size properties (config 3: 7176 x 10728 + side features, k=32, 1M rows)
+# --------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big_log():
+    sh = synth.SHAPES["kuairec_big"]
+    train, val = synth.make_log(sh, "FM", "IPS", seed=0, n_train=1_000_000, n_val=20_000)
+    return sh, train, val
+
+
+@pytest.mark.parametrize("batch", [2000, 65536])
+def test_full_size_step_properties(rfm, big_log, batch):
+    """At BASELINE's full size the oracle is too slow for whole fits, so check
+    size-independent properties: (1) step == grad + apply, (2) a step is bitwise
+    reproducible, (3) g_w0 is minus the sum of residuals and the gradient of a
+    column nobody touched is exactly zero, (4) one oracle step on the same batch."""
+    pkg, _lib, runtime, rt = rfm
+    from relevance_factorizationmachine_amd.fm import FmPlan
+    sh, train, val = big_log
+    n, k = train["features"].shape[1], sh.n_factors
+    lr = 9e-6
+    dev = runtime.DeviceCSR(rt, train["features"])
+    y = rt.upload(train["labels"], dtype=np.float64)
+    p = rt.upload(train["pscores"], dtype=np.float64)
+    plan = FmPlan(rt, dev, k, batch)
+    ids_h = runtime.sample_batches(dev.shape[0], batch, 0, 1)[0]
+    ids = rt.upload(ids_h)
+    csr = (dev.indptr.data_ptr(), dev.indices.data_ptr(), dev.values.data_ptr(), y.data_ptr(), p.data_ptr())
+
+    def fresh():
+        return _fm(pkg, n_factors=k, n_features=n, lr=lr, batch_size=batch)
+
+    def params(m):
+        return m.w0.dev.data_ptr(), m.w.dev.data_ptr(), m.V.dev.data_ptr()
+
+    a, b, c = fresh(), fresh(), fresh()
+    _lib.check(rt.lib.rfm_fm_step(rt.ctx, plan.handle, *csr, ids.data_ptr(), batch, *params(a), lr))
+    _lib.check(rt.lib.rfm_fm_step(rt.ctx, plan.handle, *csr, ids.data_ptr(), batch, *params(b), lr))
+    grad = rt.empty((n * k + n + 1,), y.dtype)
+    _lib.check(rt.lib.rfm_fm_grad(rt.ctx, plan.handle, *csr, ids.data_ptr(), batch, *params(c), grad.data_ptr()))
+    gh = grad.cpu().numpy().copy()
+    _lib.check(rt.lib.rfm_fm_apply(rt.ctx, *params(c), grad.data_ptr(), n, k, lr))
+    rt.sync()
+    Va, Vb, Vc = a.V(), b.V(), c.V()
+    np.testing.assert_array_equal(Va, Vb)  # (2) bitwise reproducible
+    np.testing.assert_array_equal(a.w(), b.w())
+    assert rel_err(Vc, Va) < 1e-14 and rel_err(c.w(), a.w()) < 1e-14  # (1)
+    # (4) one oracle step on the same rows
+    w0, w, V = cpu_ref.fm_init(12345, n, k)
+    Xb = train["features"][ids_h]
+    err, g_w0, g_w, G_V = cpu_ref.fm_gradients(Xb, train["labels"][ids_h], train["pscores"][ids_h], w0, w, V)
+    assert rel_err(gh[: n * k].reshape(n, k), G_V) < TIGHT
+    assert rel_err(gh[n * k: n * k + n], g_w) < TIGHT
+    assert abs(gh[-1] - g_w0) <= TIGHT * max(1.0, abs(g_w0))
+    assert abs(gh[-1] + np.sum(err)) <= 1e-9 * max(1.0, abs(np.sum(err)))  # (3)
+    untouched = np.setdiff1d(np.arange(n), np.unique(Xb.indices))
+    if untouched.size:
+        assert np.all(gh[: n * k].reshape(n, k)[untouched] == 0.0)
+        np.testing.assert_array_equal(Va[untouched], V[untouched])
+    assert rel_err(Va, V - lr * G_V) < TIGHT
+    plan.close()
+
+
+def test_full_size_forward_permutation_invariance(rfm, big_log):
+    pkg, _lib, runtime, rt = rfm
+    sh, train, val = big_log
+    model = _fm(pkg, n_factors=sh.n_factors, n_features=val["features"].shape[1])
+    X = val["features"]
+    base = model.predict(X)
+    perm = np.random.default_rng(0).permutation(X.shape[0])
+    np.testing.assert_array_equal(model.predict(X[perm]), base[perm])
+    w0, w, V = cpu_ref.fm_init(12345, X.shape[1], sh.n_factors)
+    assert rel_err(base, cpu_ref.fm_predict(X, w0, w, V)) < TIGHT
+
+
+def test_import_shims_resolve_to_this_package(rfm):
+    pkg = rfm[0]
+    from src.fm import FactorizationMachines as FM
+    from src.mf import LogisticMatrixFactorization as MF
+    from src.base import PointwiseBaseRecommender as Base
+    from utils.optimizer import SGD
+    assert FM is pkg.FactorizationMachines and MF is pkg.LogisticMatrixFactorization
+    assert issubclass(FM, Base) and SGD is pkg.DeviceSGD

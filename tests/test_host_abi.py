@@ -1,0 +1,96 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol the
+header declares, and its host-only entry points (sampler, MF schedule) match
+NumPy / a Python restatement.  No GPU needed."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from relevance_factorizationmachine_amd import _lib
+from relevance_factorizationmachine_amd.runtime import mf_schedule, sample_batches
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "rfm_hip.h")).read()
+    declared = sorted(set(re.findall(r"^int32_t\s+(rfm_\w+)\s*\(", header, flags=re.M)))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in rfm_hip.h but not exported"
+    assert sorted(_lib.exported_symbols()) == declared, "ctypes table and header disagree"
+    assert lib.rfm_version() == 100
+
+
+@pytest.mark.parametrize("n,batch", [(1, 1), (2, 2), (7, 3), (1000, 64), (3660, 500), (43036, 2000), (65537, 100)])
+def test_sampler_bit_exact_vs_numpy(n, batch):
+    got = sample_batches(n, batch, 0, 5, n_threads=3)
+    for e in range(5):
+        order = np.arange(n)
+        np.random.RandomState(e).shuffle(order)
+        np.testing.assert_array_equal(got[e], order[:batch])
+
+
+def test_sampler_large_and_offsets():
+    n = 1_000_000
+    got = sample_batches(n, 2000, 7, 2, n_threads=2)
+    for i, e in enumerate((7, 8)):
+        order = np.arange(n)
+        np.random.RandomState(e).shuffle(order)
+        np.testing.assert_array_equal(got[i], order[:2000])
+
+
+def test_sampler_golden(golden):
+    g = golden("batch_ids")
+    for key in g.files:
+        n, e = key[1:].split("_e")
+        np.testing.assert_array_equal(sample_batches(int(n), 32, int(e), 1)[0], g[key])
+
+
+def test_sampler_rejects_oversized_batch():
+    # the reference's resample raises ValueError (sklearn) when B > N
+    with pytest.raises(ValueError, match="Cannot sample 11 out of arrays with dim 10"):
+        sample_batches(10, 11, 0, 1)
+
+
+def _levels_py(users, items):
+    lu, li, lev = {}, {}, []
+    for u, i in zip(users, items):
+        l = max(lu.get(u, -1), li.get(i, -1)) + 1
+        lu[u] = li[i] = l
+        lev.append(l)
+    return np.asarray(lev)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_mf_schedule_matches_python(seed):
+    rng = np.random.default_rng(seed)
+    b, nu, ni = 3000, 500, 80
+    users = rng.integers(0, nu, size=b)
+    items = (rng.zipf(1.3, size=b) - 1) % ni
+    order, lptr = mf_schedule(users, items, nu, ni)
+    lev = _levels_py(users, items)
+    assert len(lptr) - 1 == lev.max() + 1
+    assert sorted(order.tolist()) == list(range(b))
+    for l in range(len(lptr) - 1):
+        grp = order[lptr[l]:lptr[l + 1]]
+        assert np.all(lev[grp] == l)
+        assert np.all(np.diff(grp) > 0)  # ascending batch position
+        # rows touched inside a level are disjoint
+        assert len(set(users[grp].tolist())) == len(grp)
+        assert len(set(items[grp].tolist())) == len(grp)
+    # called twice: the per-thread scratch is reset properly
+    order2, lptr2 = mf_schedule(users, items, nu, ni)
+    np.testing.assert_array_equal(order, order2)
+    np.testing.assert_array_equal(lptr, lptr2)
+
+
+def test_mf_schedule_edges():
+    order, lptr = mf_schedule(np.zeros(0, np.int32), np.zeros(0, np.int32), 4, 4)
+    assert order.size == 0 and lptr.tolist() == [0]
+    order, lptr = mf_schedule(np.array([1, 1, 1]), np.array([0, 2, 3]), 4, 4)
+    assert order.tolist() == [0, 1, 2] and lptr.tolist() == [0, 1, 2, 3]
+    with pytest.raises(ValueError):
+        mf_schedule(np.array([5]), np.array([0]), 4, 4)

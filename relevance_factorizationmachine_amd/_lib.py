@@ -15,7 +15,8 @@ from typing import List, Optional
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "librfm_hip.so")
+# RFM_LIB_PATH: load another build of the same ABI (timing experiments under profiles/)
+LIB_PATH = os.environ.get("RFM_LIB_PATH") or os.path.join(PKG_DIR, "librfm_hip.so")
 SOURCES = ["rfm_capi.hip", "rfm_fm.hip", "rfm_mf.hip", "rfm_host.cpp"]
 HEADERS = [os.path.join(CSRC, "rfm_common.h"),
            os.path.join(os.path.dirname(PKG_DIR), "include", "rfm_hip.h")]
@@ -35,6 +36,8 @@ def _hipcc() -> Optional[str]:
 
 
 def _stale() -> bool:
+    if os.environ.get("RFM_LIB_PATH"):
+        return False
     if not os.path.exists(LIB_PATH):
         return True
     built = os.path.getmtime(LIB_PATH)

@@ -4,27 +4,42 @@
 //   CSR of the log:   indptr int64[N+1], indices int32[nnz], values f64[nnz]
 //   parameters:       w0[1], w[n], V[n][k] row-major (the reference's NumPy layout)
 //   per-step scratch: Q[B][k] (= X_b V_old), err[B] (= y/p - sigmoid(logit))
-//   training plan:    column-major ("slot") view of the whole training CSR
+//   training plan:    columns are split in two classes when the plan is built
+//     HOT columns     (expected entries per batch >= hot_min_count, at most what
+//                     fits the LDS budget; side features, dense reals, top items):
+//                     slot_of[p] = -1 - hot_rank.  Their gradient is accumulated
+//                     on chip: every forward workgroup keeps [H][k+2] sums in LDS
+//                     (ds_add_f64) and stores ONE slab at its end.
+//     SPARSE columns  (one-hot users / items ...): a column-major ("slot") view
+//                     of the whole training CSR restricted to these columns
 //                     slot_of int32[nnz]  CSR entry -> slot (column-major rank)
-//                     csc_x   f64[nnz], csc_col int32[nnz]  value / column of a slot
-//                     slot_t  int32[nnz]  batch position of the slot's row, or -1
+//                     csc_x f64, csc_col int32   value / column of a slot
+//                     slot_t int32        batch position of the slot's row, or -1
 //
 // One training step (rfm_fm_step) is three launches on one stream:
 //   1. fm_forward_kernel   rows of the batch in parallel: q_t = V^T x_t, logit,
-//                          residual; writes Q, err and marks slot_t for the
-//                          batch's entries (plain stores, no atomics).
+//                          residual; writes Q, err, marks slot_t for the sparse
+//                          entries (plain stores) and adds the hot entries'
+//                          err_t x_tj [q_t, 1, x_tj] into the LDS sums.
 //   2. fm_consume_kernel   waves own disjoint slot windows (whole columns, or a
 //                          chunk of a long column); a wave scans its window,
 //                          accumulates sum_t err_t x_tj Q[t,:] over the marked
 //                          slots IN SLOT ORDER and updates V[j,:], w[j] in
 //                          place (or writes a chunk partial).  Resets slot_t.
-//   3. fm_finalize_kernel  long columns: partials summed in chunk order and
-//                          applied; w0 from a fixed-order sum of err.
-// No float atomics anywhere: every sum has a fixed order, so a step is bitwise
-// reproducible.  Reference arithmetic: src/fm.py:80-88,114-187 (see rfm_hip.h).
+//   3. fm_finalize_kernel  hot columns: slabs summed in block order and applied;
+//                          long sparse columns: partials summed in chunk order;
+//                          w0 from a fixed-order sum of err.
+// No global float atomics.  Sparse-class sums have a fixed order (bitwise
+// reproducible); hot-class sums inside one workgroup are LDS atomics, so their
+// last bits may vary from run to run (hot_min_count < 0 turns the class off).
+// Reference arithmetic: src/fm.py:80-88,114-187 (see rfm_hip.h).
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
+#include <numeric>
 
 #include "rfm_common.h"
 
@@ -32,7 +47,9 @@ namespace rfm {
 
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
-constexpr double kLogitClip = 700.0;  // src/base.py:65
+constexpr double kLogitClip = 700.0;      // src/base.py:65
+constexpr size_t kHotLdsBudget = 64 << 10;  // bytes of LDS a forward workgroup spends on hot sums
+constexpr int kMaxHot = 1024;
 
 // ---------------------------------------------------------------------------
 // device helpers
@@ -44,13 +61,15 @@ __device__ inline double group_sum(double v) {
   return v;
 }
 
-// fixed-order block sum (tree over LDS); result valid in thread 0
+// fixed-order block sum (tree over LDS); every thread gets the total
+template <int BLOCK>
 __device__ inline double block_sum(double v, double* lds) {
   const int tid = threadIdx.x;
+  __syncthreads();
   lds[tid] = v;
   __syncthreads();
 #pragma unroll
-  for (int s = kBlock / 2; s > 0; s >>= 1) {
+  for (int s = BLOCK / 2; s > 0; s >>= 1) {
     if (tid < s) lds[tid] += lds[tid + s];
     __syncthreads();
   }
@@ -89,7 +108,7 @@ struct Pack<2> {
 };
 
 // ---------------------------------------------------------------------------
-// 1. forward (+ residual, Q, slot marks, loss partials)
+// 1. forward (+ residual, Q, slot marks, hot sums, loss partials)
 // ---------------------------------------------------------------------------
 struct FwdArgs {
   const int64_t* indptr;
@@ -106,25 +125,43 @@ struct FwdArgs {
   double* out_pred;      // nullable
   double* out_err;       // nullable
   double* out_Q;         // nullable [n_rows][k]
-  const int32_t* slot_of;  // nullable: mark slots
+  const int32_t* slot_of;  // nullable: >=0 mark that slot, <0 hot column -1-slot_of
   int32_t* slot_t;
+  int32_t n_hot;         // hot columns (training step only)
+  double* hot_slab;      // [gridDim.x][n_hot][k+2]
   double* loss_partial;  // nullable: [gridDim.x]
   double eps;
+  int32_t ablate;  // -DRFM_ABLATE builds only: bit mask of parts to skip (timing experiments)
 };
+
+#ifdef RFM_ABLATE
+#define RFM_KEEP(a, bit) (((a).ablate & (bit)) == 0)
+#else
+#define RFM_KEEP(a, bit) true
+#endif
+// bits: 1 slot marks, 2 Q store, 4 V gathers, 8 hot LDS adds, 16 slab store, 32 hot pass entirely
 
 // A row is handled by LPR consecutive lanes; lane l holds factors
 // (c*LPR + l)*VEC .. +VEC-1 for c < NC.  k=32 -> LPR=16, VEC=2: one 16-byte
 // load per lane covers a 256-byte row of V, four rows per wave.
-template <int LPR, int VEC, int NC>
-__global__ __launch_bounds__(kBlock) void fm_forward_kernel(FwdArgs a) {
-  constexpr int GPB = kBlock / LPR;  // row groups per block
-  __shared__ double lds[kBlock];
+template <int LPR, int VEC, int NC, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fm_forward_kernel(FwdArgs a) {
+  constexpr int GPB = BLOCK / LPR;  // row groups per block
+  extern __shared__ double dyn_lds[];  // [BLOCK] reduction scratch, then [n_hot][k+2] hot sums
+  double* red = dyn_lds;
+  double* hot = dyn_lds + BLOCK;
   const int tid = threadIdx.x;
   const int l = tid % LPR;
   const int g = tid / LPR;
   const int k = a.k;
+  const int hot_w = k + 2;
   const double w0 = a.w0[0];
   double loss_acc = 0.0;
+
+  if (a.n_hot > 0) {
+    for (int i = tid; i < a.n_hot * hot_w; i += BLOCK) hot[i] = 0.0;
+    __syncthreads();
+  }
 
   for (int64_t base = int64_t(blockIdx.x) * GPB; base < a.n_rows;
        base += int64_t(gridDim.x) * GPB) {
@@ -151,7 +188,10 @@ __global__ __launch_bounds__(kBlock) void fm_forward_kernel(FwdArgs a) {
         col = a.indices[my];
         x = a.values[my];
         lin += a.w[col] * x;
-        if (a.slot_of) a.slot_t[a.slot_of[my]] = int32_t(t);
+        if (a.slot_of) {
+          const int32_t so = a.slot_of[my];
+          if (so >= 0 && RFM_KEEP(a, 1)) a.slot_t[so] = int32_t(t);
+        }
       }
       const int cnt = (p1 - pb) < int64_t(LPR) ? int(p1 - pb) : LPR;
       for (int j = 0; j < cnt; ++j) {
@@ -163,7 +203,8 @@ __global__ __launch_bounds__(kBlock) void fm_forward_kernel(FwdArgs a) {
           const int f = (c * LPR + l) * VEC;
           if (f < k) {
             Pack<VEC> pv;
-            pv.load(vrow + f);
+            if (RFM_KEEP(a, 4)) pv.load(vrow + f);
+            else pv.load(a.V + f);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
               const double vx = pv.v[v] * xj;
@@ -185,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void fm_forward_kernel(FwdArgs a) {
 
     if (valid) {
       const double pred = sigmoid_clipped(w0 + lin + 0.5 * pair);
-      if (a.out_Q) {
+      if (a.out_Q && RFM_KEEP(a, 2)) {
         double* qrow = a.out_Q + t * k;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -198,16 +239,59 @@ __global__ __launch_bounds__(kBlock) void fm_forward_kernel(FwdArgs a) {
           }
         }
       }
+      double err = 0.0;
+      if (a.out_err || a.loss_partial) {
+        const double yy = a.y[r], pp = a.pscore[r];
+        err = yy / pp - pred;
+        if (l == 0 && a.loss_partial) loss_acc += logloss_term(yy, pp, pred, a.eps);
+      }
       if (l == 0) {
         if (a.out_pred) a.out_pred[t] = pred;
-        if (a.out_err) a.out_err[t] = a.y[r] / a.pscore[r] - pred;
-        if (a.loss_partial) loss_acc += logloss_term(a.y[r], a.pscore[r], pred, a.eps);
+        if (a.out_err) a.out_err[t] = err;
+      }
+      if (a.n_hot > 0 && RFM_KEEP(a, 32)) {
+        // hot entries of this row: err * x * [q, 1, x] into the workgroup's LDS sums
+        for (int64_t pb = p0; pb < p1; pb += LPR) {
+          const int64_t my = pb + l;
+          int32_t so = 0;
+          double x = 0.0;
+          if (my < p1) {
+            so = a.slot_of[my];
+            x = a.values[my];
+          }
+          const int cnt = (p1 - pb) < int64_t(LPR) ? int(p1 - pb) : LPR;
+          for (int j = 0; j < cnt; ++j) {
+            const int32_t sj = __shfl(so, j, LPR);
+            const double xj = __shfl(x, j, LPR);
+            if (sj >= 0) continue;
+            const double coef = err * xj;
+            double* hrow = hot + (-1 - sj) * hot_w;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              const int f = (c * LPR + l) * VEC;
+              if (f < k) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                  if (RFM_KEEP(a, 8)) unsafeAtomicAdd(hrow + f + v, coef * q[c][v]);
+              }
+            }
+            if (l == 0 && RFM_KEEP(a, 8)) {
+              unsafeAtomicAdd(hrow + k, coef);
+              unsafeAtomicAdd(hrow + k + 1, coef * xj);
+            }
+          }
+        }
       }
     }
   }
 
+  if (a.n_hot > 0 && RFM_KEEP(a, 16)) {
+    __syncthreads();
+    double* slab = a.hot_slab + int64_t(blockIdx.x) * a.n_hot * hot_w;
+    for (int i = tid; i < a.n_hot * hot_w; i += BLOCK) slab[i] = hot[i];
+  }
   if (a.loss_partial) {
-    const double s = block_sum(loss_acc, lds);
+    const double s = block_sum<BLOCK>(loss_acc, red);
     if (tid == 0) a.loss_partial[blockIdx.x] = s;
   }
 }
@@ -218,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void loss_finish_kernel(const double* parti
   __shared__ double lds[kBlock];
   double acc = 0.0;
   for (int i = threadIdx.x; i < n_partial; i += kBlock) acc += partial[i];
-  const double s = block_sum(acc, lds);
+  const double s = block_sum<kBlock>(acc, lds);
   if (threadIdx.x == 0) out[0] = -s / double(n_rows);
 }
 
@@ -234,12 +318,12 @@ __global__ __launch_bounds__(kBlock) void logloss_kernel(const double* y, const 
     const int64_t r = row_ids ? int64_t(row_ids[t]) : t;
     acc += logloss_term(y[r], pscore[r], pred[t], eps);
   }
-  const double s = block_sum(acc, lds);
+  const double s = block_sum<kBlock>(acc, lds);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
 // ---------------------------------------------------------------------------
-// 2. column-owner gradient + update
+// 2. column-owner gradient + update (sparse class)
 // ---------------------------------------------------------------------------
 struct WorkItem {
   int32_t slot_begin;
@@ -313,12 +397,9 @@ __device__ inline void flush_column(ColAcc<LPR, VEC, NC>& acc, int32_t col, int3
     for (int c = 0; c < NC; ++c) {
       const int f = (c * LPR + l) * VEC;
       if (f < k) {
-        Pack<VEC> pk;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) pk.v[v] = acc.m[c][v];
         // partial rows are (k+2)-strided: 16-byte alignment is not guaranteed
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) prow[f + v] = pk.v[v];
+        for (int v = 0; v < VEC; ++v) prow[f + v] = acc.m[c][v];
       }
     }
     if (l == 0) {
@@ -443,7 +524,8 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// 3. long columns (partials in chunk order) and w0
+// 3. hot columns (slabs in block order), long sparse columns (partials in chunk
+//    order) and w0
 // ---------------------------------------------------------------------------
 struct SplitCol {
   int32_t col;
@@ -456,6 +538,10 @@ struct FinArgs {
   const SplitCol* split;
   int32_t n_split;
   const double* partials;
+  const int32_t* hot_cols;
+  int32_t n_hot;
+  const double* hot_slab;
+  int32_t n_slabs;
   const double* err;
   int64_t batch;
   int32_t k;
@@ -467,40 +553,71 @@ struct FinArgs {
   double* grad;  // nullable
 };
 
-// blocks [0, n_split): one long column each (threads over factors);
-// block n_split: w0 from the fixed-order sum of the residuals.
-__global__ __launch_bounds__(kBlock) void fm_finalize_kernel(FinArgs a) {
-  __shared__ double lds[kBlock];
-  const int k = a.k;
-  if (int(blockIdx.x) < a.n_split) {
-    const SplitCol sc = a.split[blockIdx.x];
-    double gw = 0.0, d = 0.0;
-    for (int p = 0; p < sc.part_count; ++p) {
-      const double* prow = a.partials + int64_t(sc.part_begin + p) * (k + 2);
-      gw += prow[k];
-      d += prow[k + 1];
+// tot[f] = sum_{r<rows} base[r*stride + f], f < width, in a fixed order: the
+// block's threads split into row groups x factor lanes, each group sums its
+// rows in ascending order, the groups are then added in group order.
+__device__ inline void ordered_rows_sum(const double* base, int64_t stride, int rows, int width,
+                                        double* scratch /*[kBlock]*/, double* tot /*[width]*/) {
+  int fw = 1;
+  while (fw < width && fw < kBlock) fw <<= 1;
+  const int nsg = kBlock / fw;
+  const int sg = threadIdx.x / fw, fl = threadIdx.x % fw;
+  for (int f0 = 0; f0 < width; f0 += fw) {
+    const int f = f0 + fl;
+    double acc = 0.0;
+    if (f < width)
+      for (int r = sg; r < rows; r += nsg) acc += base[int64_t(r) * stride + f];
+    __syncthreads();
+    scratch[threadIdx.x] = acc;
+    __syncthreads();
+    if (sg == 0 && f < width) {
+      double s = 0.0;
+      for (int j = 0; j < nsg; ++j) s += scratch[j * fw + fl];
+      tot[f] = s;
     }
+  }
+  __syncthreads();
+}
+
+// blocks [0, n_split): one long sparse column each; [n_split, n_split+n_hot):
+// one hot column each; last block: w0 from the fixed-order sum of the residuals.
+__global__ __launch_bounds__(kBlock) void fm_finalize_kernel(FinArgs a) {
+  __shared__ double scratch[kBlock];
+  __shared__ double tot[RFM_MAX_FACTORS + 2];
+  const int k = a.k;
+  const int b = blockIdx.x;
+  if (b < a.n_split + a.n_hot) {
+    int32_t col;
+    if (b < a.n_split) {
+      const SplitCol sc = a.split[b];
+      col = sc.col;
+      ordered_rows_sum(a.partials + int64_t(sc.part_begin) * (k + 2), k + 2, sc.part_count, k + 2,
+                       scratch, tot);
+    } else {
+      const int h = b - a.n_split;
+      col = a.hot_cols[h];
+      ordered_rows_sum(a.hot_slab + int64_t(h) * (k + 2), int64_t(a.n_hot) * (k + 2), a.n_slabs,
+                       k + 2, scratch, tot);
+    }
+    const double gw = tot[k], d = tot[k + 1];
     for (int f = threadIdx.x; f < k; f += kBlock) {
-      double m = 0.0;
-      for (int p = 0; p < sc.part_count; ++p)
-        m += a.partials[int64_t(sc.part_begin + p) * (k + 2) + f];
-      const int64_t at = int64_t(sc.col) * k + f;
+      const int64_t at = int64_t(col) * k + f;
       if (a.grad)
-        a.grad[at] = d * a.V[at] - m;
+        a.grad[at] = d * a.V[at] - tot[f];
       else
-        a.V[at] += a.lr * (m - d * a.V[at]);
+        a.V[at] += a.lr * (tot[f] - d * a.V[at]);
     }
     if (threadIdx.x == 0) {
       if (a.grad)
-        a.grad[a.n * k + sc.col] = -gw;
+        a.grad[a.n * k + col] = -gw;
       else
-        a.w[sc.col] += a.lr * gw;
+        a.w[col] += a.lr * gw;
     }
     return;
   }
   double acc = 0.0;
   for (int64_t t = threadIdx.x; t < a.batch; t += kBlock) acc += a.err[t];
-  const double s = block_sum(acc, lds);
+  const double s = block_sum<kBlock>(acc, scratch);
   if (threadIdx.x == 0) {
     if (a.grad)
       a.grad[a.n * k + a.n] = -s;
@@ -574,33 +691,74 @@ inline Shape shape_for(int k) {
     }                                                                                  \
   } while (0)
 
-inline int forward_grid(const rfm_ctx* ctx, int64_t n_rows, int lpr) {
-  const int gpb = kBlock / lpr;
-  const int64_t want = (n_rows + gpb - 1) / gpb;
-  return int(std::max<int64_t>(1, std::min<int64_t>(want, int64_t(ctx->n_cu) * 8)));
+// forward launch geometry: large workgroups (few hot-sum slabs) once the batch
+// fills the chip with them, 256-thread ones otherwise.  RFM_FWD_BLOCK /
+// RFM_FWD_PER_CU override the choice (tuning experiments only).
+struct FwdGeom {
+  int block, grid;
+};
+
+inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
 }
 
-void launch_forward(rfm_ctx* ctx, FwdArgs a, int grid_override = 0) {
+inline FwdGeom forward_geom(const rfm_ctx* ctx, int64_t n_rows, int lpr) {
+  static const int big_block = env_int("RFM_FWD_BLOCK", 512);
+  static const int per_cu = env_int("RFM_FWD_PER_CU", 3);
+  FwdGeom g;
+  const int big = (big_block == 1024 || big_block == 512) ? big_block : 256;
+  const int64_t rows_big = big / lpr;
+  if (big > 256 && (n_rows + rows_big - 1) / rows_big >= int64_t(ctx->n_cu) * per_cu) {
+    g.block = big;
+    g.grid = ctx->n_cu * per_cu;
+  } else {
+    g.block = 256;
+    const int gpb = 256 / lpr;
+    const int64_t want = (n_rows + gpb - 1) / gpb;
+    g.grid = int(std::max<int64_t>(1, std::min<int64_t>(want, int64_t(ctx->n_cu) * 8)));
+  }
+  g.grid = std::min(g.grid, 2048);
+  return g;
+}
+
+constexpr int kMaxFwdGrid = 2048;  // upper bound of forward_geom().grid, sizes scratch
+
+void launch_forward(rfm_ctx* ctx, FwdArgs a, FwdGeom geom) {
   if (a.n_rows <= 0) return;
   const Shape s = shape_for(a.k);
-  const int grid = grid_override ? grid_override : forward_grid(ctx, a.n_rows, s.lpr);
-#define RFM_CALL_FWD(L, Vv, N) \
-  hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N>), dim3(grid), dim3(kBlock), 0, ctx->stream, a)
+  const size_t lds = size_t(geom.block) * 8 + size_t(a.n_hot) * size_t(a.k + 2) * 8;
+#define RFM_CALL_FWD(L, Vv, N)                                                                   \
+  do {                                                                                           \
+    if (geom.block == 1024)                                                                      \
+      hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, 1024>), dim3(geom.grid), dim3(1024), lds,  \
+                         ctx->stream, a);                                                        \
+    else if (geom.block == 512)                                                                  \
+      hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, 512>), dim3(geom.grid), dim3(512), lds,    \
+                         ctx->stream, a);                                                        \
+    else                                                                                         \
+      hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, 256>), dim3(geom.grid), dim3(256), lds,    \
+                         ctx->stream, a);                                                        \
+  } while (0)
   RFM_FOR_SHAPE(s, RFM_CALL_FWD);
 #undef RFM_CALL_FWD
   RFM_HIP_CHECK(hipGetLastError());
 }
 
+void launch_forward(rfm_ctx* ctx, FwdArgs a) {
+  if (a.n_rows <= 0) return;
+  launch_forward(ctx, a, forward_geom(ctx, a.n_rows, shape_for(a.k).lpr));
+}
+
 // forward with loss: partials in ctx scratch, finished into d_out_loss
 void forward_loss(rfm_ctx* ctx, FwdArgs a, double* d_out_loss) {
   RFM_REQUIRE(a.n_rows > 0, "loss of zero rows");
-  const Shape s = shape_for(a.k);
-  const int grid = forward_grid(ctx, a.n_rows, s.lpr);
-  ctx->loss_partials.ensure(size_t(ctx->n_cu) * 8 * sizeof(double));
+  const FwdGeom geom = forward_geom(ctx, a.n_rows, shape_for(a.k).lpr);
+  ctx->loss_partials.ensure(size_t(std::max(kMaxFwdGrid, ctx->n_cu * 8)) * sizeof(double));
   a.loss_partial = ctx->loss_partials.as<double>();
-  launch_forward(ctx, a, grid);
+  launch_forward(ctx, a, geom);
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kBlock), 0, ctx->stream,
-                     ctx->loss_partials.as<double>(), grid, a.n_rows, d_out_loss);
+                     ctx->loss_partials.as<double>(), geom.grid, a.n_rows, d_out_loss);
   RFM_HIP_CHECK(hipGetLastError());
 }
 
@@ -611,13 +769,13 @@ void forward_loss(rfm_ctx* ctx, FwdArgs a, double* d_out_loss) {
 // ---------------------------------------------------------------------------
 struct rfm_fm_plan {
   int32_t device = 0;
-  int64_t n_rows = 0, n_features = 0, nnz = 0, max_batch = 0;
+  int64_t n_rows = 0, n_features = 0, nnz = 0, n_slots = 0, max_batch = 0;
   int32_t k = 0;
   int32_t n_items = 0, n_split = 0, n_parts = 0, n_hot = 0;
-  rfm::DevBuf slot_of, slot_t, csc_x, csc_col, items, split, partials, Q, err;
+  rfm::DevBuf slot_of, slot_t, csc_x, csc_col, items, split, partials, Q, err, hot_cols, hot_slab;
   size_t device_bytes() const {
     return slot_of.bytes + slot_t.bytes + csc_x.bytes + csc_col.bytes + items.bytes +
-           split.bytes + partials.bytes + Q.bytes + err.bytes;
+           split.bytes + partials.bytes + Q.bytes + err.bytes + hot_cols.bytes + hot_slab.bytes;
   }
 };
 
@@ -627,6 +785,7 @@ namespace {
 
 constexpr int32_t kPackSlots = 256;    // whole short columns packed per wave up to this
 constexpr int32_t kChunkSlots = 4096;  // a longer column is cut into chunks of this
+constexpr int32_t kDefaultHotMinCount = 32;
 
 void upload(DevBuf& dst, const void* src, size_t bytes, hipStream_t stream) {
   dst.alloc(bytes);
@@ -648,6 +807,7 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
                   const double* d_pscore, const int32_t* d_row_ids, int64_t batch, double* d_w0,
                   double* d_w, double* d_V, double lr, double* d_grad) {
   const int k = plan->k;
+  const Shape s = shape_for(k);
   FwdArgs f{};
   f.indptr = d_indptr;
   f.indices = d_indices;
@@ -664,15 +824,20 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   f.out_Q = plan->Q.as<double>();
   f.slot_of = plan->slot_of.as<int32_t>();
   f.slot_t = plan->slot_t.as<int32_t>();
+  f.n_hot = plan->n_hot;
+  f.hot_slab = plan->hot_slab.as<double>();
+#ifdef RFM_ABLATE
+  f.ablate = env_int("RFM_ABLATE_MASK", 0);
+#endif
+  const FwdGeom geom = forward_geom(ctx, batch, s.lpr);
   ctx->prof_mark();
-  launch_forward(ctx, f);
+  launch_forward(ctx, f, geom);
   ctx->prof_mark();
 
   if (d_grad) {
     const size_t bytes = (size_t(plan->n_features) * (k + 1) + 1) * sizeof(double);
     RFM_HIP_CHECK(hipMemsetAsync(d_grad, 0, bytes, ctx->stream));
   }
-  const Shape s = shape_for(k);
   if (plan->n_items > 0) {
     ConsArgs c{};
     c.items = plan->items.as<WorkItem>();
@@ -702,6 +867,10 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   fa.split = plan->split.as<SplitCol>();
   fa.n_split = plan->n_split;
   fa.partials = plan->partials.as<double>();
+  fa.hot_cols = plan->hot_cols.as<int32_t>();
+  fa.n_hot = plan->n_hot;
+  fa.hot_slab = plan->hot_slab.as<double>();
+  fa.n_slabs = geom.grid;
   fa.err = plan->err.as<double>();
   fa.batch = batch;
   fa.k = k;
@@ -711,8 +880,8 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   fa.V = d_V;
   fa.lr = lr;
   fa.grad = d_grad;
-  hipLaunchKernelGGL(fm_finalize_kernel, dim3(plan->n_split + 1), dim3(kBlock), 0, ctx->stream,
-                     fa);
+  hipLaunchKernelGGL(fm_finalize_kernel, dim3(plan->n_split + plan->n_hot + 1), dim3(kBlock), 0,
+                     ctx->stream, fa);
   RFM_HIP_CHECK(hipGetLastError());
   ctx->prof_mark();
 }
@@ -762,7 +931,7 @@ int32_t rfm_ips_logloss(rfm_ctx* ctx, const double* d_y, const double* d_pred,
     RFM_REQUIRE(n_rows >= 1, "loss of zero rows");
     const int grid =
         int(std::min<int64_t>((n_rows + kBlock - 1) / kBlock, int64_t(ctx->n_cu) * 8));
-    ctx->loss_partials.ensure(size_t(ctx->n_cu) * 8 * sizeof(double));
+    ctx->loss_partials.ensure(size_t(std::max(kMaxFwdGrid, ctx->n_cu * 8)) * sizeof(double));
     hipLaunchKernelGGL(logloss_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_y, d_pred,
                        d_pscore, d_row_ids, n_rows, eps, ctx->loss_partials.as<double>());
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kBlock), 0, ctx->stream,
@@ -800,28 +969,50 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
     RFM_REQUIRE(ctx && h_indptr && out, "null pointer");
     RFM_REQUIRE(n_rows >= 1 && n_features >= 1 && max_batch >= 1, "bad shape");
     (void)shape_for(n_factors);
-    (void)hot_min_count;
     const int64_t nnz = h_indptr[n_rows];
     RFM_REQUIRE(nnz >= 0 && nnz < (int64_t(1) << 31) - kWave, "nnz=%lld unsupported",
                 (long long)nnz);
     RFM_REQUIRE(nnz == 0 || (h_indices && h_values), "null CSR arrays");
     RFM_REQUIRE(n_features < (int64_t(1) << 31), "n_features too large");
+    const size_t nz = static_cast<size_t>(nnz);
+    const size_t nf = static_cast<size_t>(n_features);
 
-    // column-major rank of every CSR entry (stable: row order inside a column)
-    std::vector<int64_t> cptr(size_t(n_features) + 1, 0);
+    // column lengths
+    std::vector<int64_t> len(nf, 0);
     for (int64_t p = 0; p < nnz; ++p) {
       const int32_t c = h_indices[p];
       RFM_REQUIRE(c >= 0 && c < n_features, "column index %d out of range", c);
-      cptr[size_t(c) + 1]++;
+      len[size_t(c)]++;
     }
-    for (int64_t c = 0; c < n_features; ++c) cptr[size_t(c) + 1] += cptr[size_t(c)];
-    const size_t nz = static_cast<size_t>(nnz);
-    std::vector<int32_t> slot_of(nz), csc_col(nz);
-    std::vector<double> csc_x(nz);
+    // hot class: expected entries per batch >= hot_min, most frequent first, LDS budget
+    std::vector<int32_t> hot_cols;
+    std::vector<int32_t> hot_rank(nf, -1);
+    if (hot_min_count >= 0) {
+      const int64_t hot_min = hot_min_count > 0 ? hot_min_count : kDefaultHotMinCount;
+      for (int64_t c = 0; c < n_features; ++c)
+        if (len[size_t(c)] * max_batch >= hot_min * n_rows) hot_cols.push_back(int32_t(c));
+      std::stable_sort(hot_cols.begin(), hot_cols.end(),
+                       [&](int32_t x, int32_t y) { return len[size_t(x)] > len[size_t(y)]; });
+      const size_t cap = std::min<size_t>(kMaxHot, kHotLdsBudget / (size_t(n_factors + 2) * 8));
+      if (hot_cols.size() > cap) hot_cols.resize(cap);
+      std::sort(hot_cols.begin(), hot_cols.end());
+      for (size_t h = 0; h < hot_cols.size(); ++h) hot_rank[size_t(hot_cols[h])] = int32_t(h);
+    }
+    // column-major rank of every sparse-class entry (stable: row order inside a column)
+    std::vector<int64_t> cptr(nf + 1, 0);
+    for (size_t c = 0; c < nf; ++c) cptr[c + 1] = cptr[c] + (hot_rank[c] >= 0 ? 0 : len[c]);
+    const int64_t n_slots = cptr[nf];
+    const size_t ns = static_cast<size_t>(n_slots);
+    std::vector<int32_t> slot_of(nz), csc_col(ns);
+    std::vector<double> csc_x(ns);
     {
       std::vector<int64_t> cursor(cptr.begin(), cptr.end() - 1);
       for (int64_t p = 0; p < nnz; ++p) {
         const int32_t c = h_indices[p];
+        if (hot_rank[size_t(c)] >= 0) {
+          slot_of[size_t(p)] = -1 - hot_rank[size_t(c)];
+          continue;
+        }
         const int64_t s = cursor[size_t(c)]++;
         slot_of[size_t(p)] = int32_t(s);
         csc_col[size_t(s)] = c;
@@ -838,12 +1029,12 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
         items.push_back({int32_t(open_begin), int32_t(end), -1, 0});
       open_begin = -1;
     };
-    for (int64_t c = 0; c < n_features; ++c) {
-      const int64_t b = cptr[size_t(c)], e = cptr[size_t(c) + 1], len = e - b;
-      if (len == 0) continue;
-      if (len > kPackSlots) {
+    for (size_t c = 0; c < nf; ++c) {
+      const int64_t b = cptr[c], e = cptr[c + 1], clen = e - b;
+      if (clen == 0) continue;
+      if (clen > kPackSlots) {
         close_open(b);
-        if (len <= kChunkSlots) {
+        if (clen <= kChunkSlots) {
           items.push_back({int32_t(b), int32_t(e), -1, 0});
         } else {
           SplitCol sc{int32_t(c), n_parts, 0, 0};
@@ -858,7 +1049,7 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
       if (open_begin >= 0 && e - open_begin > kPackSlots) close_open(b);
       if (open_begin < 0) open_begin = b;
     }
-    close_open(nnz);
+    close_open(n_slots);
     // longest items first: the tail of the launch is then made of short ones
     std::stable_sort(items.begin(), items.end(), [](const WorkItem& x, const WorkItem& y) {
       return (x.slot_end - x.slot_begin) > (y.slot_end - y.slot_begin);
@@ -870,19 +1061,24 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
     plan->n_rows = n_rows;
     plan->n_features = n_features;
     plan->nnz = nnz;
+    plan->n_slots = n_slots;
     plan->max_batch = max_batch;
     plan->k = n_factors;
     plan->n_items = int32_t(items.size());
     plan->n_split = int32_t(split.size());
     plan->n_parts = n_parts;
-    upload(plan->slot_of, slot_of.data(), size_t(nnz) * 4, ctx->stream);
-    upload(plan->csc_col, csc_col.data(), size_t(nnz) * 4, ctx->stream);
-    upload(plan->csc_x, csc_x.data(), size_t(nnz) * 8, ctx->stream);
+    plan->n_hot = int32_t(hot_cols.size());
+    upload(plan->slot_of, slot_of.data(), nz * 4, ctx->stream);
+    upload(plan->csc_col, csc_col.data(), ns * 4, ctx->stream);
+    upload(plan->csc_x, csc_x.data(), ns * 8, ctx->stream);
     upload(plan->items, items.data(), items.size() * sizeof(WorkItem), ctx->stream);
     upload(plan->split, split.data(), split.size() * sizeof(SplitCol), ctx->stream);
-    plan->slot_t.alloc(size_t(nnz + kWave) * 4);
+    upload(plan->hot_cols, hot_cols.data(), hot_cols.size() * 4, ctx->stream);
+    plan->slot_t.alloc((ns + kWave) * 4);
     RFM_HIP_CHECK(hipMemsetAsync(plan->slot_t.p, 0xFF, plan->slot_t.bytes, ctx->stream));
     plan->partials.alloc(size_t(std::max(n_parts, 1)) * size_t(n_factors + 2) * 8);
+    plan->hot_slab.alloc(size_t(kMaxFwdGrid) * std::max<size_t>(hot_cols.size(), 1) *
+                         size_t(n_factors + 2) * 8);
     plan->Q.alloc(size_t(max_batch) * size_t(n_factors) * 8);
     plan->err.alloc(size_t(max_batch) * 8);
     // host vectors die at scope exit: wait for the copies

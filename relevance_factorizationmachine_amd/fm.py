@@ -67,6 +67,11 @@ class FactorizationMachines(PointwiseBaseRecommender):
     alpha: float = 2.0
     evaluator: Optional[object] = None
 
+    # Not a constructor argument: columns with at least this many expected
+    # entries per batch are summed on chip (0 = library default, -1 = never,
+    # which makes every sum's order fixed and a fit bitwise reproducible).
+    hot_min_count = 0
+
     def __post_init__(self) -> None:
         # src/fm.py:31-53 -- the reference's NumPy calls, in its draw order
         np.random.seed(self.seed)
@@ -107,7 +112,7 @@ class FactorizationMachines(PointwiseBaseRecommender):
         vy = rt.upload(np.asarray(val["labels"]), dtype=np.float64)
         vp = rt.upload(np.asarray(val["pscores"]), dtype=np.float64)
         d_ids = rt.upload(ids)
-        plan = FmPlan(rt, tr, self.n_factors, self.batch_size)
+        plan = FmPlan(rt, tr, self.n_factors, self.batch_size, self.hot_min_count)
         tl = rt.empty((self.n_epochs,), y.dtype)
         vl = rt.empty((self.n_epochs,), y.dtype)
 

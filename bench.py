@@ -107,7 +107,7 @@ def main() -> None:
     ids = sample_batches(n_train, gB, 0, W + K)  # exact resample() ids, same on every rank
     sampler_s = time.perf_counter() - t_s
     d_ids = rt.upload(ids)
-    plan = FmPlan(rt, csr, k, B)
+    plan = FmPlan(rt, csr, train["labels"], train["pscores"], k, B)
     csr_ptrs = (csr.indptr.data_ptr(), csr.indices.data_ptr(), csr.values.data_ptr(),
                 y.data_ptr(), p.data_ptr())
     params = (model.w0.dev.data_ptr(), model.w.dev.data_ptr(), model.V.dev.data_ptr())
@@ -200,7 +200,7 @@ def main() -> None:
                           "threads": min(os.cpu_count() or 1, 32)}
         if not args.no_extra and B != 2000:
             # the reference's own batch size (conf/setting/kuairec.yaml:52)
-            plan2 = FmPlan(rt, csr, k, 2000)
+            plan2 = FmPlan(rt, csr, train["labels"], train["pscores"], k, 2000)
             ids2 = rt.upload(sample_batches(n_train, 2000, 0, 200))
 
             def run2(count):

@@ -84,7 +84,9 @@ int32_t rfm_sample_batches(int64_t n_rows, int64_t batch_size, int64_t epoch_beg
  * Replaces FactorizationMachines.predict (src/fm.py:114-133) with _sigmoid
  * (src/base.py:63-66): out[t] = sigmoid(clip(w0 + sum_i w_i x_ti
  *   + 0.5 * sum_f[(sum_i v_if x_ti)^2 - sum_i v_if^2 x_ti^2], +-700))
- * for row r = d_row_ids ? d_row_ids[t] : t of the CSR matrix. */
+ * for row r = d_row_ids ? d_row_ids[t] : t of the CSR matrix.  d_indices and
+ * d_values must be readable for at least one element even if the matrix has
+ * no entries (rows without entries score sigmoid(w0)). */
 int32_t rfm_fm_forward(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_indices,
                        const double* d_values, const int32_t* d_row_ids, int64_t n_rows,
                        const double* d_w0, const double* d_w, const double* d_V,
@@ -108,17 +110,19 @@ int32_t rfm_fm_forward_loss(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t
                             double* d_out_loss);
 
 /* ---- FM: training plan --------------------------------------------------
- * One-time (per fit) column-major view of the training CSR used by the
- * atomic-free gradient: built on the host from the caller's HOST CSR arrays,
- * stored in plan-owned device memory.  max_batch bounds the batch size of
- * later steps.  hot_min_count: a column whose expected number of entries per
- * batch (its training frequency * max_batch / n_rows) reaches this value is
- * accumulated on chip per row tile instead of through its column list
- * (0 = library default, <0 = never). */
+ * One-time (per fit) device layout of the training log (train["features"],
+ * ["labels"], ["pscores"] of src/fm.py:55-79) for the gradient without global
+ * atomics: row records, entry records and a column-major view, built on the
+ * host from the caller's HOST arrays and stored in plan-owned device memory.
+ * max_batch bounds the batch size of later steps.  hot_min_count: a column
+ * whose expected number of entries per batch (its training frequency *
+ * max_batch / n_rows) reaches this value is accumulated on chip by the forward
+ * workgroups instead of through its column list (0 = library default,
+ * <0 = never: every sum then has a fixed order). */
 int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t* h_indices,
-                           const double* h_values, int64_t n_rows, int64_t n_features,
-                           int32_t n_factors, int64_t max_batch, int32_t hot_min_count,
-                           rfm_fm_plan** out);
+                           const double* h_values, const double* h_y, const double* h_pscore,
+                           int64_t n_rows, int64_t n_features, int32_t n_factors,
+                           int64_t max_batch, int32_t hot_min_count, rfm_fm_plan** out);
 int32_t rfm_fm_plan_destroy(rfm_fm_plan* plan);
 /* h_out[0]=n_work_items, [1]=n_split_columns, [2]=n_hot_columns, [3]=nnz,
  * [4]=device bytes owned by the plan */
@@ -128,8 +132,9 @@ int32_t rfm_fm_plan_info(const rfm_fm_plan* plan, int64_t* h_out5);
  * Replaces lines src/fm.py:80-88 with _update_w0/_update_w/_update_V
  * (src/fm.py:135-187) and SGD.update (utils/optimizer.py:56-64) for the batch
  * rows d_row_ids[0..batch): residual e = y/p - predict(old params); batch-SUM
- * gradients (no 1/|B|); w0, w, V updated in place with lr.  The CSR arrays are
- * the device copy of the matrix the plan was built from. */
+ * gradients (no 1/|B|); w0, w, V updated in place with lr.  The CSR / label /
+ * propensity arrays are the device copy of the log the plan was built from
+ * (the step reads the plan's own records of it). */
 int32_t rfm_fm_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
                     const int32_t* d_indices, const double* d_values, const double* d_y,
                     const double* d_pscore, const int32_t* d_row_ids, int64_t batch,

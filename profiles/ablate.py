@@ -31,7 +31,7 @@ m = FactorizationMachines(estimator="IPS", n_epochs=1, n_factors=k, lr=9e-6, bat
 csr = DeviceCSR(rt, X)
 y = rt.upload(train["labels"], dtype=np.float64); p = rt.upload(train["pscores"], dtype=np.float64)
 ids = rt.upload(sample_batches(X.shape[0], B, 0, K + 5))
-plan = FmPlan(rt, csr, k, B, int(os.environ.get("ABL_HOT", "0")))
+plan = FmPlan(rt, csr, train["labels"], train["pscores"], k, B, int(os.environ.get("ABL_HOT", "0")))
 args = (csr.indptr.data_ptr(), csr.indices.data_ptr(), csr.values.data_ptr(), y.data_ptr(), p.data_ptr())
 par = (m.w0.dev.data_ptr(), m.w.dev.data_ptr(), m.V.dev.data_ptr())
 def run(first, count):

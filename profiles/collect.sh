@@ -22,3 +22,13 @@ F=$(find "$OUT/prof" -name "*kernel_stats*.csv" | head -1)
 [ -n "$F" ] && cp "$F" "$OUT/kernel_stats.csv" && head -12 "$OUT/kernel_stats.csv"
 # the per-dispatch trace is large: keep only the stats
 find "$OUT/prof" -name "*kernel_trace*.csv" -size +2M -delete
+# HBM traffic: FETCH_SIZE and WRITE_SIZE in their own passes (TCC slots do not fit both)
+cd /tmp
+for C in fetch:FETCH_SIZE write:WRITE_SIZE; do
+  timeout -k 10 600 rocprofv3 --pmc ${C#*:} --kernel-trace --output-format csv -d "$OUT/pmc_${C%%:*}" -- \
+    python3 "$R/bench.py" "$@" --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc_${C%%:*}.err" || { echo "pmc ${C#*:} failed"; tail -5 "$OUT/pmc_${C%%:*}.err"; }
+done
+cd "$R"
+python profiles/pmc_summary.py "$OUT" 65536 "$OUT/traffic.json" > "$OUT/pmc_summary.json" 2>&1; cat "$OUT/pmc_summary.json" | head -40
+find "$OUT" -name "*kernel_trace*.csv" -size +2M -delete
+find "$OUT" -name "*counter_collection*.csv" -size +8M -delete

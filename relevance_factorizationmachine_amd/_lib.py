@@ -82,7 +82,7 @@ SIGNATURES = {
     "rfm_ips_logloss": [_vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp],
     "rfm_fm_forward_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32,
                             _f64, _vp, _vp],
-    "rfm_fm_plan_create": [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _i32, C.POINTER(_vp)],
+    "rfm_fm_plan_create": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _i32, C.POINTER(_vp)],
     "rfm_fm_plan_destroy": [_vp],
     "rfm_fm_plan_info": [_vp, _vp],
     "rfm_fm_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f64],

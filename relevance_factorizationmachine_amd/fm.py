@@ -25,13 +25,18 @@ from .runtime import CsrCache, DeviceCSR, Runtime, sample_batches
 class FmPlan:
     """Owner of an ``rfm_fm_plan`` (column-major view of a training CSR)."""
 
-    def __init__(self, rt: Runtime, csr: DeviceCSR, n_factors: int, max_batch: int,
+    def __init__(self, rt: Runtime, csr: DeviceCSR, labels, pscores, n_factors: int, max_batch: int,
                  hot_min_count: int = 0):
         self.rt = rt
+        y = np.ascontiguousarray(labels, dtype=np.float64)
+        p = np.ascontiguousarray(pscores, dtype=np.float64)
+        if y.shape[0] != csr.shape[0] or p.shape[0] != csr.shape[0]:
+            raise ValueError("labels / pscores do not match the number of rows")
         handle = C.c_void_p()
         _lib.check(rt.lib.rfm_fm_plan_create(
             rt.ctx, csr.h_indptr.ctypes.data, csr.h_indices.ctypes.data, csr.h_values.ctypes.data,
-            csr.shape[0], csr.shape[1], n_factors, max_batch, hot_min_count, C.byref(handle)))
+            y.ctypes.data, p.ctypes.data, csr.shape[0], csr.shape[1], n_factors, max_batch,
+            hot_min_count, C.byref(handle)))
         self.handle = handle
 
     def info(self) -> dict:
@@ -112,7 +117,8 @@ class FactorizationMachines(PointwiseBaseRecommender):
         vy = rt.upload(np.asarray(val["labels"]), dtype=np.float64)
         vp = rt.upload(np.asarray(val["pscores"]), dtype=np.float64)
         d_ids = rt.upload(ids)
-        plan = FmPlan(rt, tr, self.n_factors, self.batch_size, self.hot_min_count)
+        plan = FmPlan(rt, tr, train["labels"], train["pscores"], self.n_factors, self.batch_size,
+                      self.hot_min_count)
         tl = rt.empty((self.n_epochs,), y.dtype)
         vl = rt.empty((self.n_epochs,), y.dtype)
 

@@ -124,8 +124,8 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
                            int64_t n_rows, int64_t n_features, int32_t n_factors,
                            int64_t max_batch, int32_t hot_min_count, rfm_fm_plan** out);
 int32_t rfm_fm_plan_destroy(rfm_fm_plan* plan);
-/* h_out[0]=n_work_items, [1]=n_split_columns, [2]=n_hot_columns, [3]=nnz,
- * [4]=device bytes owned by the plan */
+/* h_out[0]=slot windows, [1]=columns crossing a window border, [2]=hot
+ * columns, [3]=nnz, [4]=device bytes owned by the plan */
 int32_t rfm_fm_plan_info(const rfm_fm_plan* plan, int64_t* h_out5);
 
 /* ---- FM: one training step ----------------------------------------------

@@ -47,6 +47,9 @@ print(json.dumps({"wall_us": 1e6 * wall, "fwd_us": 1e3 * ms[0] / cnt[0], "cons_u
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":  # measure in this process (for rocprofv3 -- python3 ...)
+        exec(compile(CHILD % {"root": ROOT}, "ablate_child", "exec"), {"__name__": "__main__"})
+        return
     specs = [a for a in sys.argv[1:] if "=" in a or a.isidentifier()]
     for spec in specs:
         name, _, rest = spec.partition("=")

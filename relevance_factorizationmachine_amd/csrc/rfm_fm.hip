@@ -26,15 +26,16 @@
 //                          residual; writes Q, err, marks slot_t for the sparse
 //                          entries (plain stores) and adds the hot entries'
 //                          err_t x_tj [q_t, 1, x_tj] into the LDS sums.
-//   2. fm_consume_kernel   lane groups own disjoint slot windows (whole columns,
-//                          or a chunk of a long column); a group scans its
-//                          window, accumulates err_t x_tj [Q[t,:], 1, x_tj] over
-//                          the marked slots IN SLOT ORDER and updates V[j,:],
-//                          w[j] in place (or writes a chunk partial).  Resets
-//                          the marks it consumed.
-//   3. fm_finalize_kernel  hot columns: slabs summed in block order and applied;
-//                          long sparse columns: partials summed in chunk order;
-//                          w0 from a fixed-order sum of err.
+//   2. fm_consume_kernel   one fixed window of 64 slots per lane group: the
+//                          group reads the window's marks, accumulates
+//                          err_t x_tj [Q[t,:], 1, x_tj] over the marked slots IN
+//                          SLOT ORDER, updates V[j,:], w[j] in place for columns
+//                          wholly inside the window (it is their only writer),
+//                          leaves a stamped partial ("carry") for a column that
+//                          crosses a window border, and resets the marks.
+//   3. fm_finalize_kernel  crossing columns: carries summed in window order and
+//                          applied; hot columns: slabs summed in block order;
+//                          w0 from the forward workgroups' residual sums.
 // No global float atomics.  Sparse-class sums have a fixed order (bitwise
 // reproducible); hot-class sums inside one workgroup are LDS atomics, so their
 // last bits may vary from run to run (hot_min_count < 0 turns the class off).
@@ -76,6 +77,9 @@ inline Shape shape_for(int k) {
   s.nc = nc;
   return s;
 }
+
+// slots per window of fm_consume_kernel for a lane-group width (WinShape<LPR>::WIN)
+inline int window_slots(int lpr) { return lpr >= 64 ? 64 : (lpr == 32 ? 64 : 4 * lpr); }
 
 #define RFM_FOR_SHAPE(S, CALL)                                                         \
   do {                                                                                 \
@@ -142,15 +146,17 @@ inline FwdGeom forward_geom(const rfm_ctx* ctx, int64_t n_rows, const Shape& s, 
 
 constexpr int kMaxFwdGrid = 2048;  // upper bound of forward_geom().grid, sizes scratch
 
-inline size_t forward_lds_bytes(int block, int rows, int n_hot, int k) {
-  return size_t(block) * 8 + size_t(block) * rows * sizeof(Entry) + size_t(n_hot) * size_t(k + 2) * 8;
+inline size_t forward_lds_bytes(int block, int lpr, int rows, int n_hot, int k) {
+  return size_t(block) * 8 + (size_t(block) * rows + size_t(block / lpr)) * sizeof(Entry) +
+         size_t(n_hot) * size_t(k + 2) * 8;
 }
 
 void launch_forward(rfm_ctx* ctx, FwdArgs a, FwdGeom geom) {
   if (a.n_rows <= 0) return;
   const Shape s = shape_for(a.k);
   const size_t lds =
-      forward_lds_bytes(geom.block, geom.block == 512 ? rows_in_flight(s.nc) : 1, a.n_hot, a.k);
+      forward_lds_bytes(geom.block, s.lpr, geom.block == 512 ? rows_in_flight(s.nc) : 1, a.n_hot,
+                        a.k);
 
 #define RFM_CALL_FWD(L, Vv, N)                                                                \
   do {                                                                                        \
@@ -195,13 +201,14 @@ struct rfm_fm_plan {
   int32_t device = 0;
   int64_t n_rows = 0, n_features = 0, nnz = 0, n_slots = 0, max_batch = 0;
   int32_t k = 0;
-  int32_t n_items = 0, n_split = 0, n_parts = 0, n_hot = 0;
-  rfm::DevBuf ent, rows, slot_t, slots, items, split, partials, Q, err, hot_cols, hot_slab,
-      err_partial;
+  int32_t n_win = 0, n_cross_short = 0, n_cross_long = 0, n_hot = 0;
+  int64_t step = 0;  // stamps the carries of a step
+  rfm::DevBuf ent, rows, slot_t, slots, win, cross, carry_idx, carries, Q, err, hot_cols,
+      hot_slab, err_partial;
   size_t device_bytes() const {
-    return ent.bytes + rows.bytes + slot_t.bytes + slots.bytes + items.bytes + split.bytes +
-           partials.bytes + Q.bytes + err.bytes + hot_cols.bytes + hot_slab.bytes +
-           err_partial.bytes;
+    return ent.bytes + rows.bytes + slot_t.bytes + slots.bytes + win.bytes + cross.bytes +
+           carry_idx.bytes + carries.bytes + Q.bytes + err.bytes + hot_cols.bytes +
+           hot_slab.bytes + err_partial.bytes;
   }
 };
 
@@ -209,9 +216,8 @@ using namespace rfm;
 
 namespace {
 
-constexpr int32_t kPackSlots = 128;   // whole short columns packed per lane group up to this
-constexpr int32_t kChunkSlots = 256;  // a longer column is cut into chunks of this
 constexpr int32_t kDefaultHotMinCount = 32;
+constexpr int32_t kShortCross = 8;  // crossing columns up to this many carry rows: one lane group
 
 void upload(DevBuf& dst, const void* src, size_t bytes, hipStream_t stream) {
   dst.alloc(bytes);
@@ -261,17 +267,25 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
 #endif
   const FwdGeom geom = forward_geom(ctx, batch, s, true);
   ctx->prof_mark();
-  launch_forward(ctx, f, geom);
+#ifdef RFM_ABLATE
+  if (!(f.ablate & 64))
+#endif
+    launch_forward(ctx, f, geom);
   ctx->prof_mark();
 
   if (d_grad) {
     const size_t bytes = (size_t(plan->n_features) * (k + 1) + 1) * sizeof(double);
     RFM_HIP_CHECK(hipMemsetAsync(d_grad, 0, bytes, ctx->stream));
   }
-  if (plan->n_items > 0) {
+  const double stamp = double(++plan->step);
+#ifdef RFM_ABLATE
+  if (!(f.ablate & 128))
+#endif
+  if (plan->n_win > 0) {
     ConsArgs c{};
-    c.items = plan->items.as<WorkItem>();
-    c.n_items = plan->n_items;
+    c.win = plan->win.as<WinInfo>();
+    c.n_win = plan->n_win;
+    c.n_slots = int32_t(plan->n_slots);
     c.slot_t = plan->slot_t.as<int32_t>();
     c.slots = plan->slots.as<SlotRec>();
     c.err = plan->err.as<double>();
@@ -281,10 +295,11 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
     c.V = d_V;
     c.w = d_w;
     c.lr = lr;
-    c.partials = plan->partials.as<double>();
+    c.carries = plan->carries.as<double>();
+    c.stamp = stamp;
     c.grad = d_grad;
-    const int ipb = (kBlock / kWave) * (kWave / s.lpr);  // one item per lane group
-    const int grid = (plan->n_items + ipb - 1) / ipb;
+    const int wpb = (kBlock / kWave) * (kWave / s.lpr);  // one window per lane group
+    const int grid = (plan->n_win + wpb - 1) / wpb;
 #define RFM_CALL_CONS(L, Vv, N) \
   hipLaunchKernelGGL((fm_consume_kernel<L, Vv, N>), dim3(grid), dim3(kBlock), 0, ctx->stream, c)
     RFM_FOR_SHAPE(s, RFM_CALL_CONS);
@@ -293,9 +308,12 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   }
   ctx->prof_mark();
   FinArgs fa{};
-  fa.split = plan->split.as<SplitCol>();
-  fa.n_split = plan->n_split;
-  fa.partials = plan->partials.as<double>();
+  fa.cross = plan->cross.as<CrossCol>();
+  fa.n_cross_short = plan->n_cross_short;
+  fa.n_cross_long = plan->n_cross_long;
+  fa.carry_idx = plan->carry_idx.as<int32_t>();
+  fa.carries = plan->carries.as<double>();
+  fa.stamp = stamp;
   fa.hot_cols = plan->hot_cols.as<int32_t>();
   fa.n_hot = plan->n_hot;
   fa.hot_slab = plan->hot_slab.as<double>();
@@ -308,9 +326,20 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   fa.V = d_V;
   fa.lr = lr;
   fa.grad = d_grad;
-  hipLaunchKernelGGL(fm_finalize_kernel, dim3(plan->n_split + plan->n_hot + 1), dim3(kBlock), 0,
-                     ctx->stream, fa);
-  RFM_HIP_CHECK(hipGetLastError());
+  {
+    const int gpb = kBlock / s.lpr;
+    const int nb_cross = (plan->n_cross_short + gpb - 1) / gpb;
+    const int grid = nb_cross + plan->n_cross_long + plan->n_hot + 1;
+#ifdef RFM_ABLATE
+    if (f.ablate & 256) return;
+#endif
+#define RFM_CALL_FIN(L, Vv, N)                                                                 \
+  hipLaunchKernelGGL((fm_finalize_kernel<L, Vv, N>), dim3(grid), dim3(kBlock), 0, ctx->stream, \
+                     fa, nb_cross)
+    RFM_FOR_SHAPE(s, RFM_CALL_FIN);
+#undef RFM_CALL_FIN
+    RFM_HIP_CHECK(hipGetLastError());
+  }
   ctx->prof_mark();
 }
 
@@ -435,7 +464,7 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
     const size_t ns = static_cast<size_t>(n_slots);
     std::vector<Entry> ent(nz + 1, Entry{0, 0, 0.0});  // +1: clamp target of empty logs
     std::vector<RowRec> rows(nr);
-    std::vector<SlotRec> slots(ns + 1, SlotRec{0.0, 0, 0});
+    std::vector<SlotRec> slots(ns + 256, SlotRec{0.0, 0, 0});  // padded by one window
     {
       std::vector<int64_t> cursor(cptr.begin(), cptr.end() - 1);
       for (int64_t r = 0; r < n_rows; ++r) {
@@ -456,42 +485,38 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
         }
       }
     }
-    // work items: whole short columns packed up to kPackSlots, long columns chunked
-    std::vector<WorkItem> items;
-    std::vector<SplitCol> split;
-    int32_t n_parts = 0;
-    int64_t open_begin = -1;
-    auto close_open = [&](int64_t end) {
-      if (open_begin >= 0 && end > open_begin)
-        items.push_back({int32_t(open_begin), int32_t(end), -1, 0});
-      open_begin = -1;
-    };
-    for (size_t c = 0; c < nf; ++c) {
-      const int64_t b = cptr[c], e = cptr[c + 1], clen = e - b;
-      if (clen == 0) continue;
-      if (clen > kPackSlots) {
-        close_open(b);
-        if (clen <= kChunkSlots) {
-          items.push_back({int32_t(b), int32_t(e), -1, 0});
-        } else {
-          SplitCol sc{int32_t(c), n_parts, 0, 0};
-          for (int64_t s0 = b; s0 < e; s0 += kChunkSlots) {
-            items.push_back({int32_t(s0), int32_t(std::min(e, s0 + kChunkSlots)), n_parts++, 0});
-            sc.part_count++;
-          }
-          split.push_back(sc);
-        }
-        continue;
-      }
-      if (open_begin >= 0 && e - open_begin > kPackSlots) close_open(b);
-      if (open_begin < 0) open_begin = b;
+    // fixed slot windows (one per lane group of fm_consume_kernel) and the columns
+    // that cross a window border, with the carry rows they collect in window order
+    const Shape shp = shape_for(n_factors);
+    const int64_t WIN = window_slots(shp.lpr);
+    const int64_t n_win = (n_slots + WIN - 1) / WIN;
+    RFM_REQUIRE(n_win * 2 < (int64_t(1) << 31), "too many slot windows");
+    std::vector<WinInfo> win(static_cast<size_t>(n_win) + 1, WinInfo{0, 0, 0, 0});
+    for (int64_t w = 0; w < n_win; ++w) {
+      const int64_t b0 = w * WIN, e0 = std::min(n_slots, b0 + WIN);
+      const int32_t fc = slots[size_t(b0)].col, lc = slots[size_t(e0 - 1)].col;
+      int32_t flags = 0;
+      if (cptr[size_t(fc)] < b0 || cptr[size_t(fc) + 1] > e0) flags |= 1;
+      if (lc != fc && cptr[size_t(lc) + 1] > e0) flags |= 2;
+      win[size_t(w)] = WinInfo{fc, lc, flags, 0};
     }
-    close_open(n_slots);
-    // longest items first: neighbours in a wave then have similar lengths and the
-    // tail of the launch is made of short ones
-    std::stable_sort(items.begin(), items.end(), [](const WorkItem& x, const WorkItem& y) {
-      return (x.slot_end - x.slot_begin) > (y.slot_end - y.slot_begin);
-    });
+    std::vector<CrossCol> cross_short, cross_long;
+    std::vector<int32_t> carry_idx;
+    for (size_t c = 0; c < nf; ++c) {
+      const int64_t b0 = cptr[c], e0 = cptr[c + 1];
+      if (e0 <= b0) continue;
+      const int64_t wf = b0 / WIN, wl = (e0 - 1) / WIN;
+      if (wf == wl) continue;
+      CrossCol cc{int32_t(c), int32_t(carry_idx.size()), 0, 0};
+      for (int64_t w = wf; w <= wl; ++w) {
+        const int slot = slots[size_t(w * WIN)].col == int32_t(c) ? 0 : 1;
+        carry_idx.push_back(int32_t(w * 2 + slot));
+        cc.idx_count++;
+      }
+      (cc.idx_count <= kShortCross ? cross_short : cross_long).push_back(cc);
+    }
+    std::vector<CrossCol> cross(cross_short);
+    cross.insert(cross.end(), cross_long.begin(), cross_long.end());
 
     RFM_HIP_CHECK(hipSetDevice(ctx->device));
     auto plan = std::make_unique<rfm_fm_plan>();
@@ -502,19 +527,22 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
     plan->n_slots = n_slots;
     plan->max_batch = max_batch;
     plan->k = n_factors;
-    plan->n_items = int32_t(items.size());
-    plan->n_split = int32_t(split.size());
-    plan->n_parts = n_parts;
+    plan->n_win = int32_t(n_win);
+    plan->n_cross_short = int32_t(cross_short.size());
+    plan->n_cross_long = int32_t(cross_long.size());
     plan->n_hot = int32_t(hot_cols.size());
     upload(plan->ent, ent.data(), (nz + 1) * sizeof(Entry), ctx->stream);
     upload(plan->rows, rows.data(), nr * sizeof(RowRec), ctx->stream);
-    upload(plan->slots, slots.data(), (ns + 1) * sizeof(SlotRec), ctx->stream);
-    upload(plan->items, items.data(), items.size() * sizeof(WorkItem), ctx->stream);
-    upload(plan->split, split.data(), split.size() * sizeof(SplitCol), ctx->stream);
+    upload(plan->slots, slots.data(), slots.size() * sizeof(SlotRec), ctx->stream);
+    upload(plan->win, win.data(), win.size() * sizeof(WinInfo), ctx->stream);
+    upload(plan->cross, cross.data(), cross.size() * sizeof(CrossCol), ctx->stream);
+    upload(plan->carry_idx, carry_idx.data(), carry_idx.size() * 4, ctx->stream);
     upload(plan->hot_cols, hot_cols.data(), hot_cols.size() * 4, ctx->stream);
-    plan->slot_t.alloc((ns + kWave) * 4);
+    plan->slot_t.alloc((ns + 256) * 4);
     RFM_HIP_CHECK(hipMemsetAsync(plan->slot_t.p, 0xFF, plan->slot_t.bytes, ctx->stream));
-    plan->partials.alloc(size_t(std::max(n_parts, 1)) * size_t(n_factors + 2) * 8);
+    // carry rows [n_win*2][k+3]; stamp 0 never matches a step id (they start at 1)
+    plan->carries.alloc(std::max<size_t>(size_t(n_win) * 2, 1) * size_t(n_factors + 3) * 8);
+    RFM_HIP_CHECK(hipMemsetAsync(plan->carries.p, 0, plan->carries.bytes, ctx->stream));
     plan->hot_slab.alloc(size_t(kMaxFwdGrid) * std::max<size_t>(hot_cols.size(), 1) *
                          size_t(n_factors + 2) * 8);
     plan->err_partial.alloc(size_t(kMaxFwdGrid) * 8);
@@ -537,8 +565,8 @@ int32_t rfm_fm_plan_destroy(rfm_fm_plan* plan) {
 int32_t rfm_fm_plan_info(const rfm_fm_plan* plan, int64_t* h_out5) {
   return guarded([&] {
     RFM_REQUIRE(plan && h_out5, "null pointer");
-    h_out5[0] = plan->n_items;
-    h_out5[1] = plan->n_split;
+    h_out5[0] = plan->n_win;
+    h_out5[1] = plan->n_cross_short + plan->n_cross_long;
     h_out5[2] = plan->n_hot;
     h_out5[3] = plan->nnz;
     h_out5[4] = int64_t(plan->device_bytes());

@@ -150,7 +150,7 @@ struct FwdArgs {
 //
 // REC: read the training plan's records (RowRec / Entry); otherwise the
 // caller's CSR arrays.
-// LDS (dynamic): red[BLOCK] f64 | entry buffer [BLOCK/LPR][R][LPR] Entry | hot sums [H][k+2] f64
+// LDS (dynamic): red[BLOCK] f64 | entry buffer [BLOCK/LPR][R*LPR+1] Entry | hot sums [H][k+2] f64
 template <int LPR, int VEC, int NC, int BLOCK, int R, bool REC>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 512 ? RFM_FWD_BIG_WAVES : 1)) void fm_forward_kernel(
     FwdArgs a) {
@@ -163,8 +163,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 ? RFM_FWD_BIG_WAVES : 1)) void
   const int hot_w = k + 2;
   const int H = a.n_hot;
   double* red = dyn_lds;
-  Entry* ebuf = reinterpret_cast<Entry*>(dyn_lds + BLOCK) + g * (R * LPR);  // this group's [R][LPR]
-  double* hot = dyn_lds + BLOCK + 2 * BLOCK * R;
+  // this group's [R][LPR] entry records; groups are one record apart in bank space so that
+  // the broadcast reads of different groups do not collide
+  Entry* ebuf = reinterpret_cast<Entry*>(dyn_lds + BLOCK) + g * (R * LPR + 1);
+  double* hot = dyn_lds + BLOCK + 2 * (BLOCK * R + GPB);
   const double w0 = a.w0[0];
   const int64_t last_row = a.n_rows - 1;
   double loss_acc = 0.0, err_acc = 0.0;
@@ -337,7 +339,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 ? RFM_FWD_BIG_WAVES : 1)) void
           }
         }
         const int cnt = (maxlen - pb) < LPR ? (maxlen - pb) : LPR;
-        for (int j = 0; j < cnt; ++j) {
+        // the lane groups of a wave start at different entries: rows of one log
+        // tend to hold the same hot column at the same position, and adds to one
+        // LDS address from several groups in one instruction serialise
+        const int rot = ((g % (kWave / LPR)) * cnt) / (kWave / LPR);
+        for (int jj = 0; jj < cnt; ++jj) {
+          const int j = jj + rot < cnt ? jj + rot : jj + rot - cnt;
 #pragma unroll
           for (int i = 0; i < R; ++i) {
             const Entry e = ebuf[i * LPR + j];
@@ -407,35 +414,45 @@ __global__ __launch_bounds__(kBlock) void logloss_kernel(const double* y, const 
 }
 
 // ---------------------------------------------------------------------------
-// 2. column-owner gradient + update (sparse class)
+// 2. sparse-class gradient + update: one fixed window of slots per lane group
 // ---------------------------------------------------------------------------
-struct WorkItem {
-  int32_t slot_begin;
-  int32_t slot_end;
-  int32_t part;  // >=0: chunk of a long column -> write partial[part]; -1: whole columns
-  int32_t pad;
-};
-
 struct SlotRec {  // one slot of the column-major view, 16 B
   double x;       // feature value
   int32_t col;    // feature column
   int32_t pad;
 };
 
+struct WinInfo {      // static description of one slot window, 16 B
+  int32_t first_col;  // column of the window's first slot
+  int32_t last_col;   // column of its last slot
+  int32_t flags;      // bit0: first column is not wholly inside the window
+                      // bit1: last column (!= first) continues after the window
+  int32_t pad;
+};
+
+struct WinRec {  // a marked slot of the window being processed, parked in LDS, 24 B
+  int32_t t;     // batch position of the slot's row
+  int32_t col;   // feature column
+  double coef;   // err_t * x
+  double cx;     // err_t * x * x
+};
+
 struct ConsArgs {
-  const WorkItem* items;
-  int32_t n_items;
+  const WinInfo* win;
+  int32_t n_win;
+  int32_t n_slots;
   int32_t* slot_t;
   const SlotRec* slots;
   const double* err;
   const double* Q;
   int32_t k;
-  int64_t n;     // features
-  double* V;     // apply mode: updated in place; grad mode: read only
+  int64_t n;        // features
+  double* V;        // apply mode: updated in place; grad mode: read only
   double* w;
   double lr;
-  double* partials;  // [n_parts][k+2]: M[0..k), sum coef, sum coef*x
-  double* grad;      // nullable: grad mode -> [G_V | g_w | g_w0]
+  double* carries;  // [n_win*2][k+3]: M[0..k), sum coef, sum coef*x, step stamp
+  double stamp;     // id of this step (a carry row is valid iff its stamp matches)
+  double* grad;     // nullable: grad mode -> [G_V | g_w | g_w0]
 };
 
 template <int VEC, int NC>
@@ -452,208 +469,210 @@ struct ColAcc {
   }
 };
 
-// the lane group owns column `col` (or chunk `part` of it): apply / emit
+// V[col,:] and w[col] from the sums of one column: update in place, or write the
+// gradient row (grad mode).  vold = the row as it was read before.
 template <int LPR, int VEC, int NC>
-__device__ inline void flush_column(const ColAcc<VEC, NC>& acc, int32_t col, int32_t part,
-                                    const ConsArgs& a, int l) {
+__device__ inline void apply_column(const ColAcc<VEC, NC>& acc, const Pack<VEC> (&vold)[NC],
+                                    int32_t col, double* V, double* w, double* grad, int64_t n,
+                                    int k, double lr, int l) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int f = (c * LPR + l) * VEC;
+    if (f < k) {
+      Pack<VEC> out;
+      if (grad) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) out.v[v] = acc.d * vold[c].v[v] - acc.m[c][v];
+        out.store(grad + int64_t(col) * k + f);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+          out.v[v] = vold[c].v[v] + lr * (acc.m[c][v] - acc.d * vold[c].v[v]);
+        out.store(V + int64_t(col) * k + f);
+      }
+    }
+  }
+  if (l == 0) {
+    if (grad)
+      grad[n * k + col] = -acc.gw;
+    else
+      w[col] += lr * acc.gw;
+  }
+}
+
+// slots a lane group covers: PLANES pieces of LPR consecutive slots
+template <int LPR>
+struct WinShape {
+  static constexpr int PLANES = LPR >= 64 ? 1 : (LPR == 32 ? 2 : 4);
+  static constexpr int WIN = PLANES * LPR;
+};
+
+// A finished column of a window: updated in place when it lies wholly inside the
+// window, else left as a stamped carry row for fm_finalize_kernel.
+// (A plain function, not a lambda: a closure object would live in scratch memory.)
+template <int LPR, int VEC, int NC>
+__device__ __forceinline__ void emit_column(const ColAcc<VEC, NC>& acc,
+                                            const Pack<VEC> (&vold)[NC], int32_t cur,
+                                            const WinInfo& wi, int wid, const ConsArgs& a,
+                                            int l) {
   const int k = a.k;
-  if (part >= 0) {
-    double* prow = a.partials + int64_t(part) * (k + 2);
+  const bool carry0 = cur == wi.first_col && (wi.flags & 1);
+  const bool carry1 = !carry0 && cur == wi.last_col && (wi.flags & 2);
+  if (carry0 || carry1) {
+    double* row = a.carries + (int64_t(wid) * 2 + (carry1 ? 1 : 0)) * (k + 3);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int f = (c * LPR + l) * VEC;
       if (f < k) {
-        // partial rows are (k+2)-strided: 16-byte alignment is not guaranteed
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) prow[f + v] = acc.m[c][v];
+        for (int v = 0; v < VEC; ++v) row[f + v] = acc.m[c][v];
       }
     }
     if (l == 0) {
-      prow[k] = acc.gw;
-      prow[k + 1] = acc.d;
+      row[k] = acc.gw;
+      row[k + 1] = acc.d;
+      row[k + 2] = a.stamp;
     }
-    return;
-  }
-  double* vrow = a.V + int64_t(col) * k;
-  if (a.grad) {
-    double* grow = a.grad + int64_t(col) * k;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int f = (c * LPR + l) * VEC;
-      if (f < k) {
-        Pack<VEC> pv, pg;
-        pv.load(vrow + f);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) pg.v[v] = acc.d * pv.v[v] - acc.m[c][v];
-        pg.store(grow + f);
-      }
-    }
-    if (l == 0) a.grad[a.n * k + col] = -acc.gw;
   } else {
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int f = (c * LPR + l) * VEC;
-      if (f < k) {
-        Pack<VEC> pv;
-        pv.load(vrow + f);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) pv.v[v] += a.lr * (acc.m[c][v] - acc.d * pv.v[v]);
-        pv.store(vrow + f);
-      }
-    }
-    if (l == 0) a.w[col] += a.lr * acc.gw;
+    apply_column<LPR, VEC, NC>(acc, vold, cur, a.V, a.w, a.grad, a.n, k, a.lr, l);
   }
 }
 
-// One work item per LANE GROUP (64/LPR items per wave).  The group streams its
-// slot window in pieces of PLANES x LPR slots: the marks of the NEXT piece are
-// prefetched while the current one is processed, the per-slot data of all marked
-// slots of a piece are fetched together, and the marked slots' contributions
-// err*x*[Q[t,:], 1, x] are added strictly in slot order, four Q-row gathers in
-// flight at a time.
-template <int PLANES, typename T>
-__device__ inline T plane_select(const T (&arr)[PLANES], int pl) {
-  T v = arr[0];
-#pragma unroll
-  for (int i = 1; i < PLANES; ++i) v = (pl == i) ? arr[i] : v;
-  return v;
-}
-
+// One window of WIN consecutive slots per LANE GROUP (64/LPR windows per wave):
+// every group does the same short chain -- marks -> per-slot records of the
+// marked slots -> Q rows (four gathers in flight) -> update -- and no group
+// walks a long list, so the launch is one flat wave of independent work.  The
+// marked slots' err*x*[Q[t,:], 1, x] are added strictly in slot order.  A column
+// that lies wholly inside the window is updated here (this group is its only
+// writer); a column that crosses a window border leaves a stamped partial
+// ("carry") that fm_finalize_kernel adds up in window order.
 template <int LPR, int VEC, int NC>
 __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
   constexpr int GPW = kWave / LPR;
-  constexpr int PLANES = LPR >= 64 ? 1 : (LPR == 32 ? 2 : 4);
-  constexpr int WIN = PLANES * LPR;
+  constexpr int PLANES = WinShape<LPR>::PLANES;
+  constexpr int WIN = WinShape<LPR>::WIN;
   constexpr int BATCH = 4;
   constexpr unsigned long long GMASK = LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull);
   const int lane = threadIdx.x % kWave;
   const int l = lane % LPR;
   const int g = lane / LPR;
-  const int item_id = (blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * GPW + g;
-  WorkItem it{0, 0, -1, 0};
-  if (item_id < a.n_items) it = a.items[item_id];
+  const int wid = (blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * GPW + g;
+  const bool have = wid < a.n_win;
+  const int32_t w0 = have ? wid * WIN : 0;
   const int k = a.k;
+
+  // marks of the window and its static description (independent loads; slot_t
+  // and slots are padded by one window, so no clamp is needed)
+  int32_t tk[PLANES];
+#pragma unroll
+  for (int pl = 0; pl < PLANES; ++pl) {
+    const int32_t s = w0 + pl * LPR + l;
+    const int32_t t = a.slot_t[s];
+    tk[pl] = (have && s < a.n_slots) ? t : -1;
+  }
+  const WinInfo wi = a.win[have ? wid : 0];
+  unsigned long long M = 0ull;  // bit (pl*LPR + lane): slot order
+#pragma unroll
+  for (int pl = 0; pl < PLANES; ++pl) {
+    const unsigned long long m = (__ballot(tk[pl] >= 0) >> (g * LPR)) & GMASK;
+    M |= m << ((pl * LPR) & 63);
+  }
+  if (M == 0ull) return;
+
+  // per-slot data of the whole window, loaded unconditionally so that the loads
+  // of the planes overlap; the marked slots' records are parked in LDS, indexed by
+  // their position in the window, and read back as broadcasts
+  __shared__ WinRec wrec_all[(kBlock / LPR) * WIN];
+  WinRec* wrec = wrec_all + (threadIdx.x / LPR) * WIN;
+  {
+    SlotRec sr[PLANES];
+    double ee[PLANES];
+#pragma unroll
+    for (int pl = 0; pl < PLANES; ++pl) {
+      sr[pl] = a.slots[w0 + pl * LPR + l];
+      ee[pl] = a.err[max(tk[pl], 0)];
+    }
+#pragma unroll
+    for (int pl = 0; pl < PLANES; ++pl) {
+      if (tk[pl] >= 0) {
+        a.slot_t[w0 + pl * LPR + l] = -1;
+        const double coef = ee[pl] * sr[pl].x;
+        wrec[pl * LPR + l] = WinRec{tk[pl], sr[pl].col, coef, coef * sr[pl].x};
+      }
+    }
+  }
 
   ColAcc<VEC, NC> acc;
   acc.clear();
-  int32_t cur = -1;  // column being accumulated (uniform in the lane group)
+  Pack<VEC> vold[NC];  // V row of the column being accumulated, fetched when it starts
+  int32_t cur = -1;    // that column (uniform in the lane group)
 
-  int32_t tk[PLANES], tn[PLANES];
+  while (M) {
+    int bsel[BATCH];
+    int nb = 0;
 #pragma unroll
-  for (int pl = 0; pl < PLANES; ++pl) {
-    const int32_t s = it.slot_begin + pl * LPR + l;
-    tk[pl] = (s < it.slot_end) ? a.slot_t[s] : -1;
-  }
-  for (int32_t w0 = it.slot_begin; w0 < it.slot_end; w0 += WIN) {
-#pragma unroll
-    for (int pl = 0; pl < PLANES; ++pl) {
-      const int32_t s = w0 + WIN + pl * LPR + l;
-      tn[pl] = (s < it.slot_end) ? a.slot_t[s] : -1;
-    }
-    // marked slots of this piece: bit (pl*LPR + lane) of M, i.e. slot order
-    unsigned long long M = 0ull;
-#pragma unroll
-    for (int pl = 0; pl < PLANES; ++pl) {
-      const unsigned long long m = (__ballot(tk[pl] >= 0) >> (g * LPR)) & GMASK;
-      M |= m << ((pl * LPR) & 63);
-    }
-    int32_t col[PLANES];
-    double coef[PLANES], cx[PLANES];
-    if (M) {
-      // per-slot data of the whole piece, loaded unconditionally (clamped) so
-      // that the loads of the PLANES planes overlap; unmarked slots are masked
-      SlotRec sr[PLANES];
-      double ee[PLANES];
-#pragma unroll
-      for (int pl = 0; pl < PLANES; ++pl) {
-        const int32_t s = min(w0 + pl * LPR + l, it.slot_end - 1);
-        sr[pl] = a.slots[s];
-        ee[pl] = a.err[max(tk[pl], 0)];
-      }
-#pragma unroll
-      for (int pl = 0; pl < PLANES; ++pl) {
-        const bool active = tk[pl] >= 0;
-        if (active) a.slot_t[w0 + pl * LPR + l] = -1;
-        col[pl] = active ? sr[pl].col : -1;
-        coef[pl] = active ? ee[pl] * sr[pl].x : 0.0;
-        cx[pl] = coef[pl] * sr[pl].x;
+    for (int u = 0; u < BATCH; ++u) {
+      bsel[u] = u ? bsel[0] : 0;
+      if (M) {
+        bsel[u] = __ffsll((long long)M) - 1;
+        M &= M - 1;
+        ++nb;
       }
     }
-    while (M) {
-      int bsel[BATCH];
-      int nb = 0;
+    WinRec rec[BATCH];
+    Pack<VEC> qq[BATCH][NC];
 #pragma unroll
-      for (int u = 0; u < BATCH; ++u) {
-        bsel[u] = u ? bsel[0] : 0;
-        if (M) {
-          bsel[u] = __ffsll((long long)M) - 1;
-          M &= M - 1;
-          ++nb;
-        }
+    for (int u = 0; u < BATCH; ++u) {
+      rec[u] = wrec[bsel[u]];
+#pragma unroll
+      for (int ch = 0; ch < NC; ++ch) {
+        const int f = (ch * LPR + l) * VEC;
+        qq[u][ch].load(a.Q + int64_t(rec[u].t) * k + (f < k ? f : 0));
       }
-      int32_t tt[BATCH], cc[BATCH];
-      double ff[BATCH], xx[BATCH];
-      Pack<VEC> qq[BATCH][NC];
+    }
 #pragma unroll
-      for (int u = 0; u < BATCH; ++u) {
-        const int pl = bsel[u] / LPR, ln = bsel[u] % LPR;
-        tt[u] = __shfl(plane_select<PLANES>(tk, pl), ln, LPR);
-        cc[u] = __shfl(plane_select<PLANES>(col, pl), ln, LPR);
-        ff[u] = __shfl(plane_select<PLANES>(coef, pl), ln, LPR);
-        xx[u] = __shfl(plane_select<PLANES>(cx, pl), ln, LPR);
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch) {
-          const int f = (ch * LPR + l) * VEC;
-          if (f < k) qq[u][ch].load(a.Q + int64_t(tt[u]) * k + f);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < BATCH; ++u) {
-        if (u < nb) {
-          if (cc[u] != cur) {
-            if (cur >= 0) flush_column<LPR, VEC, NC>(acc, cur, it.part, a, l);
-            acc.clear();
-            cur = cc[u];
-          }
+    for (int u = 0; u < BATCH; ++u) {
+      if (u < nb) {
+        if (rec[u].col != cur) {
+          if (cur >= 0) emit_column<LPR, VEC, NC>(acc, vold, cur, wi, wid, a, l);
+          acc.clear();
+          cur = rec[u].col;
 #pragma unroll
           for (int ch = 0; ch < NC; ++ch) {
             const int f = (ch * LPR + l) * VEC;
-            if (f < k) {
-#pragma unroll
-              for (int v = 0; v < VEC; ++v) acc.m[ch][v] += ff[u] * qq[u][ch].v[v];
-            }
+            vold[ch].load(a.V + int64_t(cur) * k + (f < k ? f : 0));
           }
-          acc.gw += ff[u];
-          acc.d += xx[u];
         }
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc.m[ch][v] += rec[u].coef * qq[u][ch].v[v];
+        acc.gw += rec[u].coef;
+        acc.d += rec[u].cx;
       }
     }
-#pragma unroll
-    for (int pl = 0; pl < PLANES; ++pl) tk[pl] = tn[pl];
   }
-  if (cur >= 0) {
-    flush_column<LPR, VEC, NC>(acc, cur, it.part, a, l);
-  } else if (it.part >= 0) {
-    // an untouched chunk still owes its (zero) partial
-    flush_column<LPR, VEC, NC>(acc, 0, it.part, a, l);
-  }
+  if (cur >= 0) emit_column<LPR, VEC, NC>(acc, vold, cur, wi, wid, a, l);
 }
 
 // ---------------------------------------------------------------------------
-// 3. hot columns (slabs in block order), long sparse columns (partials in chunk
-//    order) and w0
+// 3. columns that cross window borders (carries in window order), hot columns
+//    (slabs in block order) and w0
 // ---------------------------------------------------------------------------
-struct SplitCol {
+struct CrossCol {      // a sparse-class column spanning more than one window
   int32_t col;
-  int32_t part_begin;
-  int32_t part_count;
+  int32_t idx_begin;   // its carry rows: carry_idx[idx_begin .. +idx_count)
+  int32_t idx_count;
   int32_t pad;
 };
 
 struct FinArgs {
-  const SplitCol* split;
-  int32_t n_split;
-  const double* partials;
+  const CrossCol* cross;  // [n_cross_short | n_cross_long]
+  int32_t n_cross_short;  // few carry rows: one lane group per column
+  int32_t n_cross_long;   // many carry rows: one workgroup per column
+  const int32_t* carry_idx;
+  const double* carries;
+  double stamp;
   const int32_t* hot_cols;
   int32_t n_hot;
   const double* hot_slab;
@@ -670,27 +689,29 @@ struct FinArgs {
 
 // tot[f] = sum_{r<rows} base[r*width + f], f < width, rows contiguous, in a
 // fixed order: the block's threads split into row groups x factor lanes, each
-// group sums its rows in ascending order (8 loads in flight), the groups are
+// group sums its rows in ascending order (16 loads in flight), the groups are
 // then added in group order.
 __device__ inline void ordered_rows_sum(const double* base, int rows, int width,
                                         double* scratch /*[kBlock]*/, double* tot /*[width]*/) {
-  int fw = 1;
-  while (fw < width && fw < kBlock) fw <<= 1;
+  constexpr int U = 16;
+  const int fw = width < kBlock ? width : kBlock;  // factor lanes per row group
   const int nsg = kBlock / fw;
   const int sg = threadIdx.x / fw, fl = threadIdx.x % fw;
+  const bool live = sg < nsg;
   for (int f0 = 0; f0 < width; f0 += fw) {
     const int f = f0 + fl;
     double acc = 0.0;
-    if (f < width) {
-      for (int r = sg; r < rows; r += nsg * 8) {
-        double v[8];
+    if (live && f < width) {
+      for (int r = sg; r < rows; r += nsg * U) {
+        double v[U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < U; ++u) {
           const int rr = r + u * nsg;
-          v[u] = rr < rows ? base[int64_t(rr) * width + f] : 0.0;
+          v[u] = base[int64_t(rr < rows ? rr : r) * width + f];
+          if (rr >= rows) v[u] = 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
+        for (int u = 0; u < U; ++u) acc += v[u];
       }
     }
     __syncthreads();
@@ -705,24 +726,121 @@ __device__ inline void ordered_rows_sum(const double* base, int rows, int width,
   __syncthreads();
 }
 
-// blocks [0, n_split): one long sparse column each; [n_split, n_split+n_hot):
-// one hot column each; last block: w0 from the forward workgroups' residual sums.
-__global__ __launch_bounds__(kBlock) void fm_finalize_kernel(FinArgs a) {
+// Same for the stamped carry rows of one long crossing column: row r is
+// carries[idx[r]], valid iff its stamp is this step's.
+__device__ inline void ordered_carry_sum(const double* carries, const int32_t* idx, int rows,
+                                         int k, double stamp, double* scratch, double* tot) {
+  constexpr int U = 8;
+  const int width = k + 2;
+  const int fw = width < kBlock ? width : kBlock;
+  const int nsg = kBlock / fw;
+  const int sg = threadIdx.x / fw, fl = threadIdx.x % fw;
+  const bool live = sg < nsg;
+  for (int f0 = 0; f0 < width; f0 += fw) {
+    const int f = f0 + fl;
+    double acc = 0.0;
+    if (live && f < width) {
+      for (int r = sg; r < rows; r += nsg * U) {
+        const double* row[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int rr = r + u * nsg;
+          row[u] = carries + int64_t(idx[rr < rows ? rr : r]) * (k + 3);
+        }
+        double v[U], st[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          v[u] = row[u][f];
+          st[u] = row[u][k + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += (r + u * nsg < rows && st[u] == stamp) ? v[u] : 0.0;
+      }
+    }
+    __syncthreads();
+    scratch[threadIdx.x] = acc;
+    __syncthreads();
+    if (sg == 0 && f < width) {
+      double s = 0.0;
+      for (int j = 0; j < nsg; ++j) s += scratch[j * fw + fl];
+      tot[f] = s;
+    }
+  }
+  __syncthreads();
+}
+
+// blocks [0, nb_cross): short crossing columns, one per lane group; then one block
+// per long crossing column; then one block per hot column; last block: w0 from the
+// forward workgroups' residual sums.
+template <int LPR, int VEC, int NC>
+__global__ __launch_bounds__(kBlock) void fm_finalize_kernel(FinArgs a, int nb_cross) {
   __shared__ double scratch[kBlock];
   __shared__ double tot[1024 + 2];
   const int k = a.k;
   const int b = blockIdx.x;
-  if (b < a.n_split + a.n_hot) {
+  if (b < nb_cross) {
+    constexpr int GPB = kBlock / LPR;
+    const int l = threadIdx.x % LPR;
+    const int ci = b * GPB + threadIdx.x / LPR;
+    if (ci >= a.n_cross_short) return;
+    const CrossCol cc = a.cross[ci];
+    ColAcc<VEC, NC> acc;
+    acc.clear();
+    Pack<VEC> vold[NC];
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) {
+      const int f = (ch * LPR + l) * VEC;
+      vold[ch].load(a.V + int64_t(cc.col) * k + (f < k ? f : 0));
+    }
+    bool any = false;
+    constexpr int CB = 4;  // carry rows per trip, loaded unconditionally; stale rows are masked
+    for (int i = 0; i < cc.idx_count; i += CB) {
+      const double* row[CB];
+      bool in[CB];
+#pragma unroll
+      for (int u = 0; u < CB; ++u) {
+        in[u] = i + u < cc.idx_count;
+        row[u] = a.carries + int64_t(a.carry_idx[cc.idx_begin + (in[u] ? i + u : i)]) * (k + 3);
+      }
+      double mm[CB][NC][VEC], gg[CB], dd[CB], ss[CB];
+#pragma unroll
+      for (int u = 0; u < CB; ++u) {
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+          const int f = (ch * LPR + l) * VEC;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) mm[u][ch][v] = row[u][(f < k ? f : 0) + v];
+        }
+        gg[u] = row[u][k];
+        dd[u] = row[u][k + 1];
+        ss[u] = row[u][k + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < CB; ++u) {
+        const bool ok = in[u] && ss[u] == a.stamp;
+        any = any || ok;
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc.m[ch][v] += ok ? mm[u][ch][v] : 0.0;
+        acc.gw += ok ? gg[u] : 0.0;
+        acc.d += ok ? dd[u] : 0.0;
+      }
+    }
+    if (any) apply_column<LPR, VEC, NC>(acc, vold, cc.col, a.V, a.w, a.grad, a.n, k, a.lr, l);
+    return;
+  }
+  const int hb = b - nb_cross - a.n_cross_long;
+  if (hb < a.n_hot) {
     int32_t col;
-    if (b < a.n_split) {
-      const SplitCol sc = a.split[b];
-      col = sc.col;
-      ordered_rows_sum(a.partials + int64_t(sc.part_begin) * (k + 2), sc.part_count, k + 2,
-                       scratch, tot);
+    if (hb < 0) {
+      const CrossCol cc = a.cross[a.n_cross_short + (b - nb_cross)];
+      col = cc.col;
+      ordered_carry_sum(a.carries, a.carry_idx + cc.idx_begin, cc.idx_count, k, a.stamp, scratch,
+                        tot);
     } else {
-      const int h = b - a.n_split;
-      col = a.hot_cols[h];
-      ordered_rows_sum(a.hot_slab + int64_t(h) * a.n_slabs * (k + 2), a.n_slabs, k + 2, scratch,
+      col = a.hot_cols[hb];
+      ordered_rows_sum(a.hot_slab + int64_t(hb) * a.n_slabs * (k + 2), a.n_slabs, k + 2, scratch,
                        tot);
     }
     const double gw = tot[k], d = tot[k + 1];

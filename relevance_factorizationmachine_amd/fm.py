@@ -42,7 +42,7 @@ class FmPlan:
     def info(self) -> dict:
         out = np.zeros(5, dtype=np.int64)
         _lib.check(self.rt.lib.rfm_fm_plan_info(self.handle, out.ctypes.data))
-        return dict(zip(("work_items", "split_columns", "hot_columns", "nnz", "device_bytes"),
+        return dict(zip(("windows", "crossing_columns", "hot_columns", "nnz", "device_bytes"),
                         (int(v) for v in out)))
 
     def close(self) -> None:

@@ -345,23 +345,34 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 ? RFM_FWD_BIG_WAVES : 1)) void
         const int rot = ((g % (kWave / LPR)) * cnt) / (kWave / LPR);
         for (int jj = 0; jj < cnt; ++jj) {
           const int j = jj + rot < cnt ? jj + rot : jj + rot - cnt;
+          Entry eh[R];
+          bool on[R];
 #pragma unroll
           for (int i = 0; i < R; ++i) {
-            const Entry e = ebuf[i * LPR + j];
-            if (e.slot >= 0 || pb + j >= len[i]) continue;
-            const double coef = err[i] * e.x;
-            double* hrow = hot + (-1 - e.slot) * hot_w;
+            eh[i] = ebuf[i * LPR + j];
+            on[i] = eh[i].slot < 0 && pb + j < len[i];
+          }
+          // two rows of the group holding the same hot column: one add for both
+          const bool pair01 = R == 2 && on[0] && on[R - 1] && eh[0].slot == eh[R - 1].slot;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-              if (fok[c]) {
+          for (int i = 0; i < R; ++i) {
+            if (!on[i] || (pair01 && i == R - 1)) continue;
+            const double coef = err[i] * eh[i].x;
+            const double coef2 = pair01 ? err[R - 1] * eh[R - 1].x : 0.0;
+            double* hrow = hot + (-1 - eh[i].slot) * hot_w;
+            if (RFM_KEEP(a, 8)) {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v)
-                  if (RFM_KEEP(a, 8)) unsafeAtomicAdd(hrow + fo[c] + v, coef * q[i][c][v]);
+              for (int c = 0; c < NC; ++c) {
+                if (fok[c]) {
+#pragma unroll
+                  for (int v = 0; v < VEC; ++v)
+                    unsafeAtomicAdd(hrow + fo[c] + v, coef * q[i][c][v] + coef2 * q[R - 1][c][v]);
+                }
               }
-            }
-            if (l == 0 && RFM_KEEP(a, 8)) {
-              unsafeAtomicAdd(hrow + k, coef);
-              unsafeAtomicAdd(hrow + k + 1, coef * e.x);
+              // sum coef (lane 0) and sum coef*x (lane 1) in one instruction
+              if (l < 2)
+                unsafeAtomicAdd(hrow + k + l, l == 0 ? coef + coef2
+                                                     : coef * eh[i].x + coef2 * eh[R - 1].x);
             }
           }
         }

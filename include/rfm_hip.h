@@ -208,6 +208,17 @@ int32_t rfm_mf_sgd_levels(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d
                           double* d_Q, double* d_bu, double* d_bi, double b,
                           int32_t n_factors, double lr, double reg);
 
+/* HOGWILD-style variant of the same batch (NOT the reference's semantics): all
+ * examples of the batch are updated concurrently without ordering, so examples
+ * sharing a user or an item race.  Throughput mode for very large batches; its
+ * results match the reference only at the loss / ranking level, not 1e-5 on the
+ * parameters.  d_pos_rows[s] is the training row of batch position s. */
+int32_t rfm_mf_sgd_hogwild(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d_items,
+                           const double* d_y, const double* d_pscore,
+                           const int32_t* d_pos_rows, int64_t batch, double* d_P, double* d_Q,
+                           double* d_bu, double* d_bi, double b, int32_t n_factors, double lr,
+                           double reg);
+
 #ifdef __cplusplus
 }
 #endif

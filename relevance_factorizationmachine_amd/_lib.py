@@ -96,6 +96,8 @@ SIGNATURES = {
     "rfm_mf_schedule": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, C.POINTER(_i32)],
     "rfm_mf_sgd_levels": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
                           _f64, _i32, _f64, _f64],
+    "rfm_mf_sgd_hogwild": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _i32, _f64,
+                           _f64],
 }
 
 _lib = None

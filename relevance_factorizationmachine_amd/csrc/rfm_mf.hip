@@ -153,7 +153,7 @@ struct MfSgdArgs {
   const double* y;
   const double* pscore;
   const int32_t* pos_rows;   // batch position -> training row
-  const int32_t* order;      // batch positions grouped by level
+  const int32_t* order;      // batch positions grouped by level (null: identity)
   const int32_t* level_ptr;  // device copy (sequential kernel only)
   int32_t lo, hi;            // wide kernel: order[lo, hi); seq kernel: levels [lo, hi)
   double* P;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_sgd_wide_kernel(MfSgdArgs a) {
   const int g = threadIdx.x / LPR;
   for (int64_t idx = int64_t(a.lo) + int64_t(blockIdx.x) * GPB + g; idx < a.hi;
        idx += int64_t(gridDim.x) * GPB)
-    mf_example<LPR, VEC, NC>(a, a.order[idx], l);
+    mf_example<LPR, VEC, NC>(a, a.order ? a.order[idx] : int32_t(idx), l);
 }
 
 // levels [lo, hi) by one workgroup, barrier between levels
@@ -423,6 +423,46 @@ int32_t rfm_mf_sgd_levels(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d
         lev = end;
       }
     }
+    RFM_HIP_CHECK(hipGetLastError());
+  });
+}
+
+int32_t rfm_mf_sgd_hogwild(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d_items,
+                           const double* d_y, const double* d_pscore,
+                           const int32_t* d_pos_rows, int64_t batch, double* d_P, double* d_Q,
+                           double* d_bu, double* d_bi, double b, int32_t n_factors, double lr,
+                           double reg) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx && d_users && d_items && d_y && d_pscore && d_pos_rows && d_P && d_Q &&
+                    d_bu && d_bi,
+                "null pointer");
+    RFM_REQUIRE(batch >= 0 && batch < (int64_t(1) << 31), "batch out of range");
+    if (batch == 0) return;
+    const MfShape s = mf_shape_for(n_factors);
+    MfSgdArgs a{};
+    a.users = d_users;
+    a.items = d_items;
+    a.y = d_y;
+    a.pscore = d_pscore;
+    a.pos_rows = d_pos_rows;
+    a.order = nullptr;  // batch order, all examples at once
+    a.lo = 0;
+    a.hi = int32_t(batch);
+    a.P = d_P;
+    a.Q = d_Q;
+    a.bu = d_bu;
+    a.bi = d_bi;
+    a.b = b;
+    a.k = n_factors;
+    a.lr = lr;
+    a.reg = reg;
+    const int gpb = kMfBlock / s.lpr;
+    const int grid = int(std::min<int64_t>((batch + gpb - 1) / gpb, int64_t(ctx->n_cu) * 8));
+#define RFM_CALL_HOG(L, Vv, N)                                                                \
+  hipLaunchKernelGGL((mf_sgd_wide_kernel<L, Vv, N>), dim3(grid), dim3(kMfBlock), 0, ctx->stream, \
+                     a)
+    RFM_MF_FOR_SHAPE(s, RFM_CALL_HOG);
+#undef RFM_CALL_HOG
     RFM_HIP_CHECK(hipGetLastError());
   });
 }

@@ -50,10 +50,11 @@ class DataParallelStep:
 
 
 def hip_fm_worker(rt, plan, csr, y, p, d_ids, global_batch: int, model, grad, world: int, rank: int,
-                  lr: float) -> DataParallelStep:
+                  lr: float, all_reduce=None) -> DataParallelStep:
     """Bind ``DataParallelStep`` to the HIP kernels.  ``d_ids`` holds the GLOBAL
     batches, ``(n_iters, global_batch)`` int32 on the device; ``grad`` is a
-    float64 device tensor of ``n*(k+1)+1`` elements."""
+    float64 device tensor of ``n*(k+1)+1`` elements.  ``all_reduce`` defaults to
+    ``torch.distributed.all_reduce`` (RCCL when the group's backend is nccl)."""
     import torch.distributed as dist
 
     from . import _lib
@@ -73,7 +74,7 @@ def hip_fm_worker(rt, plan, csr, y, p, d_ids, global_batch: int, model, grad, wo
     def apply_fn(g) -> None:
         _lib.check(rt.lib.rfm_fm_apply(rt.ctx, *params, g.data_ptr(), n, k, float(lr)))
 
-    def all_reduce(g) -> None:
+    def default_all_reduce(g) -> None:
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
 
-    return DataParallelStep(grad, grad_fn, apply_fn, all_reduce, world, rank)
+    return DataParallelStep(grad, grad_fn, apply_fn, all_reduce or default_all_reduce, world, rank)

@@ -48,6 +48,12 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
     alpha: float = 4.0
     evaluator: Optional[object] = None
 
+    # Not a constructor argument.  False (default): the reference's strictly
+    # sequential per-example updates, reproduced exactly through the level
+    # schedule.  True: HOGWILD-style unordered updates (rfm_mf_sgd_hogwild) -- a
+    # throughput mode whose parameters do NOT match the reference to 1e-5.
+    hogwild = False
+
     def __post_init__(self) -> None:
         # src/mf.py:34-66 -- the reference's NumPy calls, in its draw order
         np.random.seed(self.seed)
@@ -104,15 +110,21 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
 
         for epoch in range(self.n_epochs):
             rows = ids[epoch]
-            order, level_ptr = mf_schedule(tr.h_users[rows], tr.h_items[rows], self.n_users,
-                                           self.n_items)
-            d_order, d_lptr = rt.upload(order), rt.upload(level_ptr)
-            keep.append((d_order, d_lptr))
             ids_ptr = d_ids.data_ptr() + epoch * self.batch_size * 4
-            _lib.check(rt.lib.rfm_mf_sgd_levels(
-                rt.ctx, tr.users.data_ptr(), tr.items.data_ptr(), y.data_ptr(), p.data_ptr(),
-                ids_ptr, d_order.data_ptr(), level_ptr.ctypes.data, d_lptr.data_ptr(),
-                len(level_ptr) - 1, *params, b, self.n_factors, float(self.lr), float(self.reg)))
+            if self.hogwild:
+                _lib.check(rt.lib.rfm_mf_sgd_hogwild(
+                    rt.ctx, tr.users.data_ptr(), tr.items.data_ptr(), y.data_ptr(), p.data_ptr(),
+                    ids_ptr, self.batch_size, *params, b, self.n_factors, float(self.lr),
+                    float(self.reg)))
+            else:
+                order, level_ptr = mf_schedule(tr.h_users[rows], tr.h_items[rows], self.n_users,
+                                               self.n_items)
+                d_order, d_lptr = rt.upload(order), rt.upload(level_ptr)
+                keep.append((d_order, d_lptr))
+                _lib.check(rt.lib.rfm_mf_sgd_levels(
+                    rt.ctx, tr.users.data_ptr(), tr.items.data_ptr(), y.data_ptr(), p.data_ptr(),
+                    ids_ptr, d_order.data_ptr(), level_ptr.ctypes.data, d_lptr.data_ptr(),
+                    len(level_ptr) - 1, *params, b, self.n_factors, float(self.lr), float(self.reg)))
             # train loss on the same batch with the updated parameters (src/mf.py:110-116)
             _lib.check(rt.lib.rfm_mf_predict_loss(
                 rt.ctx, tr.users.data_ptr(), tr.items.data_ptr(), y.data_ptr(), p.data_ptr(),

@@ -245,6 +245,25 @@ def test_mf_fit_vs_oracle(rfm, k, batch):
     assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
 
 
+def test_mf_hogwild_is_a_labelled_non_parity_mode(rfm):
+    """HOGWILD updates race on shared users/items (updates of a popular item are
+    lost), so it learns more slowly than the sequential result and its parameters
+    differ: it is a throughput mode, never the graded path."""
+    pkg = rfm[0]
+    sh = synth.SHAPES["kuairec_small"]
+    train, val = synth.make_log(sh, "MF", "IPS", seed=0)
+    kw = dict(estimator="IPS", n_epochs=20, n_factors=16, lr=0.01, batch_size=2000, seed=12345,
+              n_users=sh.n_users, n_items=sh.n_items, reg=0.5)
+    exact = pkg.LogisticMatrixFactorization(**kw)
+    tr_e, va_e = exact.fit(train, val)
+    hog = pkg.LogisticMatrixFactorization(**kw)
+    hog.hogwild = True
+    tr_h, va_h = hog.fit(train, val)
+    assert np.all(np.isfinite(va_h)) and va_h[-1] < va_h[0]
+    assert va_e[-1] < va_e[0]
+    assert rel_err(hog.P(), exact.P()) > 1e-9  # not the reference's result: documented
+
+
 # --------------------------------------------------------------------------
 # full-size properties (config 3: 7176 x 10728 + side features, k=32, 1M rows)
 # --------------------------------------------------------------------------

@@ -52,8 +52,9 @@ static_assert(RFM_MAX_FACTORS <= 1024, "fm_finalize_kernel's LDS totals hold 102
 
 namespace rfm {
 
-// bytes of LDS a forward workgroup spends on the hot class sums
-constexpr size_t kHotLdsBudget = 32 << 10;
+// bytes of LDS a forward workgroup spends on the hot class sums: with the 4 KiB of
+// reduction scratch and the 16.5 KiB entry buffer, two 512-thread workgroups fit a CU
+constexpr size_t kHotLdsBudget = 56 << 10;
 constexpr int kMaxHot = 1024;
 
 // ---------------------------------------------------------------------------
@@ -452,7 +453,9 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
       std::stable_sort(hot_cols.begin(), hot_cols.end(),
                        [&](int32_t x, int32_t y) { return len[size_t(x)] > len[size_t(y)]; });
       const size_t per_col = size_t(n_factors + 2) * 8;
-      const size_t cap = std::min<size_t>(kMaxHot, kHotLdsBudget / per_col);
+      // RFM_HOT_LDS_KB overrides the LDS budget (tuning experiments only)
+      const size_t budget = size_t(env_int("RFM_HOT_LDS_KB", int(kHotLdsBudget >> 10))) << 10;
+      const size_t cap = std::min<size_t>(kMaxHot, budget / per_col);
       if (hot_cols.size() > cap) hot_cols.resize(cap);
       std::sort(hot_cols.begin(), hot_cols.end());
       for (size_t h = 0; h < hot_cols.size(); ++h) hot_rank[size_t(hot_cols[h])] = int32_t(h);

@@ -278,17 +278,22 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 ? RFM_FWD_BIG_WAVES : 1)) void
 #pragma unroll
           for (int c = 0; c < NC; ++c) pv[i][c].load(vrow + fo[c]);
         }
+        // padding entries carry x = 0 and lanes past k get a zero multiplier: the
+        // products vanish without a select or branch, so the gathers above stay
+        // unconditional and in flight together (a non-finite V entry would turn
+        // such a product into NaN -- training has diverged by then anyway)
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          const bool act = pb + j < len[i];
 #pragma unroll
-          for (int c = 0; c < NC; ++c)
+          for (int c = 0; c < NC; ++c) {
+            const double xm = fok[c] ? ej[i].x : 0.0;
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-              const double vx = (act && fok[c]) ? pv[i][c].v[v] * ej[i].x : 0.0;
+              const double vx = pv[i][c].v[v] * xm;
               q[i][c][v] += vx;
               s2[i] += vx * vx;
             }
+          }
         }
       }
     }

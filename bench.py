@@ -63,6 +63,9 @@ def main() -> None:
     ap.add_argument("--batch-size", type=int, default=65536, help="rows per GPU per step")
     ap.add_argument("--n-train", type=int, default=0, help="rows of the synthetic log (0 = config)")
     ap.add_argument("--workload", default="kuairec_big")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse "
+                         "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -80,9 +83,13 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
+    device = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(args.backend)
 
     shape = synth.SHAPES[args.workload]
     n_train = args.n_train or shape.n_train
@@ -97,7 +104,7 @@ def main() -> None:
     n = X.shape[1]
     z = X.nnz / X.shape[0]
 
-    rt = Runtime.get(local_rank)
+    rt = Runtime.get(device)
     model = FactorizationMachines(estimator="IPS", n_epochs=K, n_factors=k, lr=lr, batch_size=B,
                                   seed=seed, n_features=n)
     csr = DeviceCSR(rt, X)
@@ -119,7 +126,13 @@ def main() -> None:
                 lr, None, None, None, None, None, 0, 1e-8, None, None))
     else:
         grad = rt.empty((n * (k + 1) + 1,), torch.float64)
-        worker = hip_fm_worker(rt, plan, csr, y, p, d_ids, gB, model, grad, world, rank, lr)
+        all_reduce = None
+        if args.backend != "nccl":  # rehearsal transport: stage through the host
+            def all_reduce(g):
+                h = g.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                g.copy_(h)
+        worker = hip_fm_worker(rt, plan, csr, y, p, d_ids, gB, model, grad, world, rank, lr, all_reduce)
 
         def run(first: int, count: int) -> None:
             for it in range(first, first + count):
@@ -137,7 +150,7 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = K * gB / elapsed
@@ -163,6 +176,8 @@ def main() -> None:
             "batch_size_per_gpu": B,
             "global_batch": gB,
             "parallelism": f"dp{world}" if world > 1 else "single",
+            "collective": (f"all-reduce(sum) of the dense [G_V|g_w|g_w0] buffer, {8 * (n * (k + 1) + 1) / 1e6:.1f} MB, "
+                           f"torch.distributed/{args.backend}") if world > 1 else None,
         },
     }
 

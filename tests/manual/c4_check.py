@@ -2,7 +2,7 @@
 """Config 4 (1M users x 100k items, n = 1.1M features, k = 64, V = 563 MB) on one GPU:
 one step against the oracle's closed-form gradients, then step timings."""
 import ctypes as C, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from oracle import cpu_ref

@@ -2,9 +2,9 @@
 """fit() wall time exactly as the reference runs it (step + train-loss forward +
 val-loss forward per iteration, src/fm.py:71-102), GPU vs the CPU oracle's
 reference-structured step.  Timing experiment for DESIGN.md, not the headline bench.
-usage: python profiles/fit_bench.py <shape> <k> <batch> <epochs> [cpu_epochs]"""
+usage: python tests/manual/fit_bench.py <shape> <k> <batch> <epochs> [cpu_epochs]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import relevance_factorizationmachine_amd as pkg

@@ -208,6 +208,19 @@ int32_t rfm_mf_sgd_levels(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d
                           double* d_Q, double* d_bu, double* d_bi, double b,
                           int32_t n_factors, double lr, double reg);
 
+/* ---- multi-GPU exchange (RCCL over xGMI) ----------------------------------
+ * The data-parallel FM step all-reduces the dense gradient buffer of rfm_fm_grad
+ * (SURVEY.md 8e).  The Python mirror does that through torch.distributed (backend
+ * "nccl" is RCCL); these entry points are the same collective for callers
+ * without torch: rank 0 draws an id (128 bytes) and hands it to the other ranks
+ * by any means, every rank calls rfm_comm_init on its own ctx (one process per
+ * GPU), then rfm_allreduce_sum sums d_buf[0..count) in place over all ranks on
+ * the ctx stream.  librccl.so is loaded on first use. */
+int32_t rfm_comm_unique_id(uint8_t* h_out128);
+int32_t rfm_comm_init(rfm_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t* h_id128);
+int32_t rfm_allreduce_sum(rfm_ctx* ctx, double* d_buf, int64_t count);
+int32_t rfm_comm_destroy(rfm_ctx* ctx);
+
 /* HOGWILD-style variant of the same batch (NOT the reference's semantics): all
  * examples of the batch are updated concurrently without ordering, so examples
  * sharing a user or an item race.  Throughput mode for very large batches; its

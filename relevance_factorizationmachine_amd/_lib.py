@@ -17,8 +17,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 # RFM_LIB_PATH: load another build of the same ABI (timing experiments under profiles/)
 LIB_PATH = os.environ.get("RFM_LIB_PATH") or os.path.join(PKG_DIR, "librfm_hip.so")
-SOURCES = ["rfm_capi.hip", "rfm_fm.hip", "rfm_mf.hip", "rfm_host.cpp"]
-HEADERS = [os.path.join(CSRC, "rfm_common.h"),
+SOURCES = ["rfm_capi.hip", "rfm_fm.hip", "rfm_mf.hip", "rfm_host.cpp", "rfm_comm.cpp"]
+HEADERS = [os.path.join(CSRC, "rfm_common.h"), os.path.join(CSRC, "rfm_fm_kernels.hpp"),
            os.path.join(os.path.dirname(PKG_DIR), "include", "rfm_hip.h")]
 
 RFM_OK, RFM_ERR_BAD_ARG, RFM_ERR_HIP, RFM_ERR_NO_DEVICE, RFM_ERR_INTERNAL = range(5)
@@ -54,7 +54,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         raise RfmError("hipcc not found: cannot build librfm_hip.so (set HIPCC or install ROCm)")
     tmp = LIB_PATH + ".tmp.%d" % os.getpid()
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread"]
+           "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, capture_output=True, text=True)
@@ -96,6 +96,10 @@ SIGNATURES = {
     "rfm_mf_schedule": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, C.POINTER(_i32)],
     "rfm_mf_sgd_levels": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
                           _f64, _i32, _f64, _f64],
+    "rfm_comm_unique_id": [_vp],
+    "rfm_comm_init": [_vp, _i32, _i32, _vp],
+    "rfm_allreduce_sum": [_vp, _vp, _i64],
+    "rfm_comm_destroy": [_vp],
     "rfm_mf_sgd_hogwild": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _i32, _f64,
                            _f64],
 }

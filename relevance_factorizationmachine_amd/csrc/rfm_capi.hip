@@ -31,6 +31,7 @@ int32_t rfm_destroy(rfm_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) (void)rfm_comm_destroy(ctx);
     delete ctx;
   });
 }

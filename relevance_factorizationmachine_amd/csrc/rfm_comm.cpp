@@ -1,0 +1,105 @@
+// Direct RCCL binding of librfm_hip.so: the all-reduce(sum) of the dense FM
+// gradient buffer over xGMI for callers that do not go through
+// torch.distributed.  librccl.so is opened on first use (dlopen), so the library
+// itself loads on hosts without RCCL.
+#include <dlfcn.h>
+
+#include "rfm_common.h"
+
+namespace {
+
+// the handful of RCCL declarations used (rccl.h: ncclGetUniqueId, ncclCommInitRank,
+// ncclAllReduce, ncclCommDestroy, ncclGetErrorString; ncclFloat64 = 8, ncclSum = 0)
+constexpr int kNcclUniqueIdBytes = 128;
+struct UniqueId {
+  char internal[kNcclUniqueIdBytes];
+};
+using Comm = void*;
+struct Rccl {
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*CommDestroy)(Comm) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+
+const Rccl& rccl() {
+  static Rccl api = [] {
+    Rccl a;
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) rfm::fail(RFM_ERR_INTERNAL, "cannot load librccl.so: %s", dlerror());
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy)
+      rfm::fail(RFM_ERR_INTERNAL, "librccl.so lacks an expected symbol");
+    return a;
+  }();
+  return api;
+}
+
+void check_rccl(int rc, const char* what) {
+  if (rc != 0) {
+    const Rccl& a = rccl();
+    rfm::fail(RFM_ERR_HIP, "%s failed: %s", what, a.GetErrorString ? a.GetErrorString(rc) : "?");
+  }
+}
+
+}  // namespace
+
+using namespace rfm;
+
+extern "C" {
+
+int32_t rfm_comm_unique_id(uint8_t* h_out128) {
+  return guarded([&] {
+    RFM_REQUIRE(h_out128, "null pointer");
+    UniqueId id;
+    check_rccl(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+    std::memcpy(h_out128, id.internal, kNcclUniqueIdBytes);
+  });
+}
+
+int32_t rfm_comm_init(rfm_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t* h_id128) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx && h_id128, "null pointer");
+    RFM_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "bad rank %d of %d", rank, n_ranks);
+    RFM_REQUIRE(ctx->comm == nullptr, "communicator already initialised");
+    RFM_HIP_CHECK(hipSetDevice(ctx->device));
+    UniqueId id;
+    std::memcpy(id.internal, h_id128, kNcclUniqueIdBytes);
+    Comm comm = nullptr;
+    check_rccl(rccl().CommInitRank(&comm, n_ranks, id, rank), "ncclCommInitRank");
+    ctx->comm = comm;
+    ctx->comm_ranks = n_ranks;
+  });
+}
+
+int32_t rfm_allreduce_sum(rfm_ctx* ctx, double* d_buf, int64_t count) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx && d_buf, "null pointer");
+    RFM_REQUIRE(ctx->comm, "rfm_comm_init has not been called");
+    RFM_REQUIRE(count >= 0, "negative count");
+    if (count == 0) return;
+    check_rccl(rccl().AllReduce(d_buf, d_buf, size_t(count), /*ncclFloat64*/ 8, /*ncclSum*/ 0,
+                                ctx->comm, ctx->stream),
+               "ncclAllReduce");
+  });
+}
+
+int32_t rfm_comm_destroy(rfm_ctx* ctx) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx, "null ctx");
+    if (!ctx->comm) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    check_rccl(rccl().CommDestroy(ctx->comm), "ncclCommDestroy");
+    ctx->comm = nullptr;
+    ctx->comm_ranks = 0;
+  });
+}
+
+}  // extern "C"

@@ -99,6 +99,8 @@ struct rfm_ctx {
   int32_t n_cu = 256;
   rfm::DevBuf loss_partials;  // per-block partial sums of the loss reduction
   rfm::DevBuf pred_scratch;   // scores when the caller does not want them
+  void* comm = nullptr;       // RCCL communicator (rfm_comm_init), or null
+  int32_t comm_ranks = 0;
   // per-kernel timing (rfm_profile_begin/end): 4 events per recorded step
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;

@@ -89,3 +89,26 @@ def test_two_rank_data_parallel_matches_single_gpu_step(tmp_path):
         assert rel_err(o["w0"], model.w0()) < 1e-12
     np.testing.assert_array_equal(outs[0]["V"], outs[1]["V"])  # replicas stay identical
     plan.close()
+
+
+def test_rccl_binding_single_rank():
+    """The C ABI's own RCCL all-reduce: with one rank it must leave the buffer
+    unchanged (multi-rank runs need one GPU per rank)."""
+    import ctypes as C
+    import torch
+    from relevance_factorizationmachine_amd import _lib
+    from relevance_factorizationmachine_amd.runtime import Runtime
+
+    rt = Runtime.get(0)
+    uid = (C.c_uint8 * 128)()
+    _lib.check(rt.lib.rfm_comm_unique_id(uid))
+    _lib.check(rt.lib.rfm_comm_init(rt.ctx, 1, 0, uid))
+    try:
+        x = torch.arange(1000, dtype=torch.float64, device=rt.torch_device)
+        _lib.check(rt.lib.rfm_allreduce_sum(rt.ctx, x.data_ptr(), 1000))
+        rt.sync()
+        np.testing.assert_array_equal(x.cpu().numpy(), np.arange(1000, dtype=np.float64))
+        with pytest.raises(ValueError):
+            _lib.check(rt.lib.rfm_comm_init(rt.ctx, 1, 0, uid))  # already initialised
+    finally:
+        _lib.check(rt.lib.rfm_comm_destroy(rt.ctx))

@@ -66,6 +66,8 @@ def main() -> None:
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse "
                          "the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--no-direct-rccl", action="store_true",
+                    help="multi-GPU: exchange through torch.distributed instead of the C ABI's RCCL binding")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -74,7 +76,7 @@ def main() -> None:
     import torch.distributed as dist
 
     from relevance_factorizationmachine_amd import _lib, synth
-    from relevance_factorizationmachine_amd.dist import hip_fm_worker
+    from relevance_factorizationmachine_amd.dist import hip_fm_train_dp, hip_fm_worker, init_direct_rccl
     from relevance_factorizationmachine_amd.fm import FactorizationMachines, FmPlan
     from relevance_factorizationmachine_amd.runtime import DeviceCSR, Runtime, sample_batches
 
@@ -119,6 +121,7 @@ def main() -> None:
                 y.data_ptr(), p.data_ptr())
     params = (model.w0.dev.data_ptr(), model.w.dev.data_ptr(), model.V.dev.data_ptr())
 
+    transport = None
     if world == 1:
         def run(first: int, count: int) -> None:
             _lib.check(rt.lib.rfm_fm_train(
@@ -133,10 +136,26 @@ def main() -> None:
                 dist.all_reduce(h, op=dist.ReduceOp.SUM)
                 g.copy_(h)
         worker = hip_fm_worker(rt, plan, csr, y, p, d_ids, gB, model, grad, world, rank, lr, all_reduce)
+        # preferred: the whole loop in one C call with RCCL on the compute stream; if RCCL
+        # cannot be bound directly, the same steps go through torch.distributed
+        direct = False
+        if args.backend == "nccl" and not args.no_direct_rccl:
+            try:
+                init_direct_rccl(rt, world, rank)
+                direct = True
+            except Exception as exc:  # noqa: BLE001
+                print(f"[rank {rank}] direct RCCL unavailable ({exc}); using torch.distributed", file=sys.stderr)
+            flag = torch.tensor([1 if direct else 0], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks or none
+            direct = bool(flag.item())
+        transport = "rccl-direct" if direct else f"torch.distributed/{args.backend}"
 
         def run(first: int, count: int) -> None:
-            for it in range(first, first + count):
-                worker.step(it, gB)
+            if direct:
+                hip_fm_train_dp(rt, plan, d_ids, gB, first, count, model, grad, world, rank, lr)
+            else:
+                for it in range(first, first + count):
+                    worker.step(it, gB)
 
     def fence() -> None:
         if world > 1:
@@ -177,7 +196,7 @@ def main() -> None:
             "global_batch": gB,
             "parallelism": f"dp{world}" if world > 1 else "single",
             "collective": (f"all-reduce(sum) of the dense [G_V|g_w|g_w0] buffer, {8 * (n * (k + 1) + 1) / 1e6:.1f} MB, "
-                           f"torch.distributed/{args.backend}") if world > 1 else None,
+                           f"{transport}") if world > 1 else None,
         },
     }
 

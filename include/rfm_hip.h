@@ -221,6 +221,18 @@ int32_t rfm_comm_init(rfm_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t
 int32_t rfm_allreduce_sum(rfm_ctx* ctx, double* d_buf, int64_t count);
 int32_t rfm_comm_destroy(rfm_ctx* ctx);
 
+/* The data-parallel fit() loop of one rank, enqueued on the ctx stream without any
+ * host synchronisation: for iteration it in [0, n_iters) the rank computes the
+ * gradient of rows d_ids[it*global_batch + shard_lo .. + shard_hi) (its contiguous
+ * shard of the global batch; an empty shard contributes zeros), all-reduces d_grad
+ * over the ranks of rfm_comm_init (skipped when no communicator or one rank), and
+ * applies theta -= lr * grad -- the same update on every rank.  d_grad is scratch
+ * of n_features*(n_factors+1)+1 doubles. */
+int32_t rfm_fm_train_dp(rfm_ctx* ctx, rfm_fm_plan* plan, const int32_t* d_ids,
+                        int64_t global_batch, int64_t shard_lo, int64_t shard_hi,
+                        int64_t n_iters, double* d_w0, double* d_w, double* d_V, double lr,
+                        double* d_grad);
+
 /* HOGWILD-style variant of the same batch (NOT the reference's semantics): all
  * examples of the batch are updated concurrently without ordering, so examples
  * sharing a user or an item race.  Throughput mode for very large batches; its

@@ -90,6 +90,7 @@ SIGNATURES = {
     "rfm_fm_apply": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64],
     "rfm_fm_train": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _f64,
                      _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp],
+    "rfm_fm_train_dp": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f64, _vp],
     "rfm_mf_predict": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _i32, _vp],
     "rfm_mf_predict_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _i32,
                             _f64, _vp, _vp],

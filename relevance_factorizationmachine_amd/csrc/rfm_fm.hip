@@ -616,6 +616,38 @@ int32_t rfm_fm_apply(rfm_ctx* ctx, double* d_w0, double* d_w, double* d_V,
   });
 }
 
+int32_t rfm_fm_train_dp(rfm_ctx* ctx, rfm_fm_plan* plan, const int32_t* d_ids,
+                        int64_t global_batch, int64_t shard_lo, int64_t shard_hi,
+                        int64_t n_iters, double* d_w0, double* d_w, double* d_V, double lr,
+                        double* d_grad) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx && plan && d_ids && d_w0 && d_w && d_V && d_grad, "null pointer");
+    RFM_REQUIRE(n_iters >= 0 && global_batch >= 1, "bad shape");
+    RFM_REQUIRE(0 <= shard_lo && shard_lo <= shard_hi && shard_hi <= global_batch, "bad shard");
+    RFM_REQUIRE(shard_hi - shard_lo <= plan->max_batch, "shard larger than the plan's max_batch");
+    const int64_t count = plan->n_features * int64_t(plan->k + 1) + 1;
+    const int64_t nk = plan->n_features * int64_t(plan->k);
+    const int apply_grid =
+        int(std::min<int64_t>((count + kBlock - 1) / kBlock, int64_t(ctx->n_cu) * 16));
+    for (int64_t it = 0; it < n_iters; ++it) {
+      if (shard_hi > shard_lo) {
+        enqueue_step(ctx, plan, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     d_ids + it * global_batch + shard_lo, shard_hi - shard_lo, d_w0, d_w, d_V,
+                     0.0, d_grad);
+      } else {
+        RFM_HIP_CHECK(hipMemsetAsync(d_grad, 0, size_t(count) * sizeof(double), ctx->stream));
+      }
+      if (ctx->comm && ctx->comm_ranks > 1) {
+        const int32_t rc = rfm_allreduce_sum(ctx, d_grad, count);
+        if (rc != RFM_OK) throw Error(rc, "all-reduce of the gradient failed (see above)");
+      }
+      hipLaunchKernelGGL(fm_apply_kernel, dim3(apply_grid), dim3(kBlock), 0, ctx->stream, d_V,
+                         d_w, d_w0, d_grad, nk, plan->n_features, lr);
+      RFM_HIP_CHECK(hipGetLastError());
+    }
+  });
+}
+
 int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
                      const int32_t* d_indices, const double* d_values, const double* d_y,
                      const double* d_pscore, const int32_t* d_ids, int64_t batch,

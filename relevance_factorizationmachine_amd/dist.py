@@ -78,3 +78,35 @@ def hip_fm_worker(rt, plan, csr, y, p, d_ids, global_batch: int, model, grad, wo
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
 
     return DataParallelStep(grad, grad_fn, apply_fn, all_reduce or default_all_reduce, world, rank)
+
+
+def init_direct_rccl(rt, world: int, rank: int) -> None:
+    """Give the runtime's context its own RCCL communicator (``rfm_comm_init``): rank 0
+    draws the id and the existing torch.distributed group carries it to the others."""
+    import ctypes as C
+
+    import torch.distributed as dist
+
+    from . import _lib
+
+    uid = (C.c_uint8 * 128)()
+    if rank == 0:
+        _lib.check(rt.lib.rfm_comm_unique_id(uid))
+    box = [bytes(uid)]
+    dist.broadcast_object_list(box, src=0)
+    buf = (C.c_uint8 * 128).from_buffer_copy(box[0])
+    _lib.check(rt.lib.rfm_comm_init(rt.ctx, world, rank, buf))
+
+
+def hip_fm_train_dp(rt, plan, d_ids, global_batch: int, first: int, count: int, model, grad,
+                    world: int, rank: int, lr: float) -> None:
+    """``count`` data-parallel iterations starting at ``first`` in one C call
+    (``rfm_fm_train_dp``): gradient of this rank's shard, RCCL all-reduce on the
+    compute stream, identical apply -- no host round trip between the three."""
+    from . import _lib
+
+    lo, hi = shard_bounds(global_batch, world, rank)
+    _lib.check(rt.lib.rfm_fm_train_dp(
+        rt.ctx, plan.handle, d_ids.data_ptr() + first * global_batch * 4, global_batch, lo, hi, count,
+        model.w0.dev.data_ptr(), model.w.dev.data_ptr(), model.V.dev.data_ptr(), float(lr),
+        grad.data_ptr()))

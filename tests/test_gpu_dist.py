@@ -112,3 +112,28 @@ def test_rccl_binding_single_rank():
             _lib.check(rt.lib.rfm_comm_init(rt.ctx, 1, 0, uid))  # already initialised
     finally:
         _lib.check(rt.lib.rfm_comm_destroy(rt.ctx))
+
+
+def test_train_dp_single_rank_equals_step():
+    """rfm_fm_train_dp with the whole batch as this rank's shard (no exchange) is
+    grad + apply of every iteration, i.e. the fused step."""
+    import torch
+    from relevance_factorizationmachine_amd import _lib
+    from relevance_factorizationmachine_amd.dist import hip_fm_train_dp
+
+    rt, model, csr, y, p, plan, ids = _setup()
+    grad = rt.empty((model.n_features * (K + 1) + 1,), torch.float64)
+    hip_fm_train_dp(rt, plan, ids, BATCH, 0, N_STEPS, model, grad, 1, 0, LR)
+    rt.sync()
+    rt2, ref, csr2, y2, p2, plan2, ids2 = _setup()
+    for it in range(N_STEPS):
+        _lib.check(rt2.lib.rfm_fm_step(rt2.ctx, plan2.handle, csr2.indptr.data_ptr(), csr2.indices.data_ptr(),
+                                       csr2.values.data_ptr(), y2.data_ptr(), p2.data_ptr(),
+                                       ids2.data_ptr() + it * BATCH * 4, BATCH, ref.w0.dev.data_ptr(),
+                                       ref.w.dev.data_ptr(), ref.V.dev.data_ptr(), LR))
+    rt2.sync()
+    assert rel_err(model.V(), ref.V()) < 1e-13
+    assert rel_err(model.w(), ref.w()) < 1e-13
+    assert rel_err(model.w0(), ref.w0()) < 1e-13
+    plan.close()
+    plan2.close()

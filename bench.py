@@ -141,8 +141,7 @@ def main() -> None:
         direct = False
         if args.backend == "nccl" and not args.no_direct_rccl:
             try:
-                init_direct_rccl(rt, world, rank)
-                direct = True
+                direct = init_direct_rccl(rt, world, rank)
             except Exception as exc:  # noqa: BLE001
                 print(f"[rank {rank}] direct RCCL unavailable ({exc}); using torch.distributed", file=sys.stderr)
             flag = torch.tensor([1 if direct else 0], device="cuda")

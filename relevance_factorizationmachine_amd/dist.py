@@ -80,22 +80,30 @@ def hip_fm_worker(rt, plan, csr, y, p, d_ids, global_batch: int, model, grad, wo
     return DataParallelStep(grad, grad_fn, apply_fn, all_reduce or default_all_reduce, world, rank)
 
 
-def init_direct_rccl(rt, world: int, rank: int) -> None:
+def init_direct_rccl(rt, world: int, rank: int) -> bool:
     """Give the runtime's context its own RCCL communicator (``rfm_comm_init``): rank 0
-    draws the id and the existing torch.distributed group carries it to the others."""
+    draws the id and the existing torch.distributed group carries it to the others.
+    Returns False on every rank (and touches nothing) if rank 0 cannot bind RCCL."""
     import ctypes as C
 
     import torch.distributed as dist
 
     from . import _lib
 
-    uid = (C.c_uint8 * 128)()
+    box = [None]
     if rank == 0:
-        _lib.check(rt.lib.rfm_comm_unique_id(uid))
-    box = [bytes(uid)]
-    dist.broadcast_object_list(box, src=0)
+        uid = (C.c_uint8 * 128)()
+        try:
+            _lib.check(rt.lib.rfm_comm_unique_id(uid))
+            box = [bytes(uid)]
+        except Exception:  # noqa: BLE001 -- reported by the caller through the False result
+            box = [None]
+    dist.broadcast_object_list(box, src=0)  # every rank takes part, success or not
+    if box[0] is None:
+        return False
     buf = (C.c_uint8 * 128).from_buffer_copy(box[0])
     _lib.check(rt.lib.rfm_comm_init(rt.ctx, world, rank, buf))
+    return True
 
 
 def hip_fm_train_dp(rt, plan, d_ids, global_batch: int, first: int, count: int, model, grad,

@@ -33,9 +33,10 @@
 //                          wholly inside the window (it is their only writer),
 //                          leaves a stamped partial ("carry") for a column that
 //                          crosses a window border, and resets the marks.
+//                          Extra workgroups of the same launch reduce the hot
+//                          columns' slabs in block order and apply them.
 //   3. fm_finalize_kernel  crossing columns: carries summed in window order and
-//                          applied; hot columns: slabs summed in block order;
-//                          w0 from the forward workgroups' residual sums.
+//                          applied; w0 from the forward workgroups' residual sums.
 // No global float atomics.  Sparse-class sums have a fixed order (bitwise
 // reproducible); hot-class sums inside one workgroup are LDS atomics, so their
 // last bits may vary from run to run (hot_min_count < 0 turns the class off).
@@ -279,10 +280,7 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
     RFM_HIP_CHECK(hipMemsetAsync(d_grad, 0, bytes, ctx->stream));
   }
   const double stamp = double(++plan->step);
-#ifdef RFM_ABLATE
-  if (!(f.ablate & 128))
-#endif
-  if (plan->n_win > 0) {
+  {
     ConsArgs c{};
     c.win = plan->win.as<WinInfo>();
     c.n_win = plan->n_win;
@@ -300,12 +298,22 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
     c.stamp = stamp;
     c.grad = d_grad;
     const int wpb = (kBlock / kWave) * (kWave / s.lpr);  // one window per lane group
-    const int grid = (plan->n_win + wpb - 1) / wpb;
+    c.nb_win = (plan->n_win + wpb - 1) / wpb;
+    c.hot_cols = plan->hot_cols.as<int32_t>();
+    c.n_hot = plan->n_hot;
+    c.hot_slab = plan->hot_slab.as<double>();
+    c.n_slabs = geom.grid;
+    const int grid = c.nb_win + plan->n_hot;  // windows, then one workgroup per hot column
+#ifdef RFM_ABLATE
+    if (!(f.ablate & 128))
+#endif
+    if (grid > 0) {
 #define RFM_CALL_CONS(L, Vv, N) \
   hipLaunchKernelGGL((fm_consume_kernel<L, Vv, N>), dim3(grid), dim3(kBlock), 0, ctx->stream, c)
-    RFM_FOR_SHAPE(s, RFM_CALL_CONS);
+      RFM_FOR_SHAPE(s, RFM_CALL_CONS);
 #undef RFM_CALL_CONS
-    RFM_HIP_CHECK(hipGetLastError());
+      RFM_HIP_CHECK(hipGetLastError());
+    }
   }
   ctx->prof_mark();
   FinArgs fa{};
@@ -315,9 +323,6 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   fa.carry_idx = plan->carry_idx.as<int32_t>();
   fa.carries = plan->carries.as<double>();
   fa.stamp = stamp;
-  fa.hot_cols = plan->hot_cols.as<int32_t>();
-  fa.n_hot = plan->n_hot;
-  fa.hot_slab = plan->hot_slab.as<double>();
   fa.n_slabs = geom.grid;
   fa.err_partial = plan->err_partial.as<double>();
   fa.k = k;
@@ -330,7 +335,7 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   {
     const int gpb = kBlock / s.lpr;
     const int nb_cross = (plan->n_cross_short + gpb - 1) / gpb;
-    const int grid = nb_cross + plan->n_cross_long + plan->n_hot + 1;
+    const int grid = nb_cross + plan->n_cross_long + 1;
 #ifdef RFM_ABLATE
     if (f.ablate & 256) return;
 #endif

@@ -430,6 +430,114 @@ __global__ __launch_bounds__(kBlock) void logloss_kernel(const double* y, const 
 }
 
 // ---------------------------------------------------------------------------
+// fixed-order reductions over rows of a table (used by launches 2 and 3)
+// ---------------------------------------------------------------------------
+// tot[f] = sum_{r<rows} base[r*width + f], f < width, rows contiguous, in a
+// fixed order: the block's threads split into row groups x factor lanes, each
+// group sums its rows in ascending order (16 loads in flight), the groups are
+// then added in group order.
+__device__ inline void ordered_rows_sum(const double* base, int rows, int width,
+                                        double* scratch /*[kBlock]*/, double* tot /*[width]*/) {
+  constexpr int U = 16;
+  const int fw = width < kBlock ? width : kBlock;  // factor lanes per row group
+  const int nsg = kBlock / fw;
+  const int sg = threadIdx.x / fw, fl = threadIdx.x % fw;
+  const bool live = sg < nsg;
+  for (int f0 = 0; f0 < width; f0 += fw) {
+    const int f = f0 + fl;
+    double acc = 0.0;
+    if (live && f < width) {
+      for (int r = sg; r < rows; r += nsg * U) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int rr = r + u * nsg;
+          v[u] = base[int64_t(rr < rows ? rr : r) * width + f];
+          if (rr >= rows) v[u] = 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u];
+      }
+    }
+    __syncthreads();
+    scratch[threadIdx.x] = acc;
+    __syncthreads();
+    if (sg == 0 && f < width) {
+      double s = 0.0;
+      for (int j = 0; j < nsg; ++j) s += scratch[j * fw + fl];
+      tot[f] = s;
+    }
+  }
+  __syncthreads();
+}
+
+// Same for the stamped carry rows of one long crossing column: row r is
+// carries[idx[r]], valid iff its stamp is this step's.
+__device__ inline void ordered_carry_sum(const double* carries, const int32_t* idx, int rows,
+                                         int k, double stamp, double* scratch, double* tot) {
+  constexpr int U = 8;
+  const int width = k + 2;
+  const int fw = width < kBlock ? width : kBlock;
+  const int nsg = kBlock / fw;
+  const int sg = threadIdx.x / fw, fl = threadIdx.x % fw;
+  const bool live = sg < nsg;
+  for (int f0 = 0; f0 < width; f0 += fw) {
+    const int f = f0 + fl;
+    double acc = 0.0;
+    if (live && f < width) {
+      for (int r = sg; r < rows; r += nsg * U) {
+        const double* row[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int rr = r + u * nsg;
+          row[u] = carries + int64_t(idx[rr < rows ? rr : r]) * (k + 3);
+        }
+        double v[U], st[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          v[u] = row[u][f];
+          st[u] = row[u][k + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += (r + u * nsg < rows && st[u] == stamp) ? v[u] : 0.0;
+      }
+    }
+    __syncthreads();
+    scratch[threadIdx.x] = acc;
+    __syncthreads();
+    if (sg == 0 && f < width) {
+      double s = 0.0;
+      for (int j = 0; j < nsg; ++j) s += scratch[j * fw + fl];
+      tot[f] = s;
+    }
+  }
+  __syncthreads();
+}
+
+// One hot column: its slabs (one per forward workgroup) summed in block order,
+// then V[col,:], w[col] updated (or the gradient row written).  Whole workgroup.
+__device__ inline void hot_column_block(int h, const int32_t* hot_cols, const double* hot_slab,
+                                        int n_slabs, int k, int64_t n, double* V, double* w,
+                                        double lr, double* grad, double* scratch, double* tot) {
+  const int32_t col = hot_cols[h];
+  ordered_rows_sum(hot_slab + int64_t(h) * n_slabs * (k + 2), n_slabs, k + 2, scratch, tot);
+  const double gw = tot[k], d = tot[k + 1];
+  for (int f = threadIdx.x; f < k; f += kBlock) {
+    const int64_t at = int64_t(col) * k + f;
+    if (grad)
+      grad[at] = d * V[at] - tot[f];
+    else
+      V[at] += lr * (tot[f] - d * V[at]);
+  }
+  if (threadIdx.x == 0) {
+    if (grad)
+      grad[n * k + col] = -gw;
+    else
+      w[col] += lr * gw;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // 2. sparse-class gradient + update: one fixed window of slots per lane group
 // ---------------------------------------------------------------------------
 struct SlotRec {  // one slot of the column-major view, 16 B
@@ -469,6 +577,13 @@ struct ConsArgs {
   double* carries;  // [n_win*2][k+3]: M[0..k), sum coef, sum coef*x, step stamp
   double stamp;     // id of this step (a carry row is valid iff its stamp matches)
   double* grad;     // nullable: grad mode -> [G_V | g_w | g_w0]
+  // hot columns ride in the same launch: the workgroups after the windows reduce
+  // the forward's slabs (independent of the sparse class, so the two overlap)
+  int32_t nb_win;   // workgroups that process windows
+  const int32_t* hot_cols;
+  int32_t n_hot;
+  const double* hot_slab;
+  int32_t n_slabs;
 };
 
 template <int VEC, int NC>
@@ -569,10 +684,22 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
   constexpr int WIN = WinShape<LPR>::WIN;
   constexpr int BATCH = 4;
   constexpr unsigned long long GMASK = LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull);
+  // LDS: the windows' parked records, or (hot-column workgroups) reduction scratch
+  constexpr int kWrecBytes = (kBlock / LPR) * WIN * int(sizeof(WinRec));
+  constexpr int kHotBytes = (kBlock + 1024 + 2) * int(sizeof(double));
+  __shared__ double lds_raw[(kWrecBytes > kHotBytes ? kWrecBytes : kHotBytes) / 8];
+  // the hot-column workgroups come last in the grid (measured: first, they delay
+  // the windows and the launch takes 4 us longer)
+  if (int(blockIdx.x) >= a.nb_win) {
+    hot_column_block(int(blockIdx.x) - a.nb_win, a.hot_cols, a.hot_slab, a.n_slabs, a.k, a.n, a.V,
+                     a.w, a.lr, a.grad, lds_raw, lds_raw + kBlock);
+    return;
+  }
+  const int wblock = int(blockIdx.x);
   const int lane = threadIdx.x % kWave;
   const int l = lane % LPR;
   const int g = lane / LPR;
-  const int wid = (blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * GPW + g;
+  const int wid = (wblock * (kBlock / kWave) + threadIdx.x / kWave) * GPW + g;
   const bool have = wid < a.n_win;
   const int32_t w0 = have ? wid * WIN : 0;
   const int k = a.k;
@@ -598,8 +725,7 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
   // per-slot data of the whole window, loaded unconditionally so that the loads
   // of the planes overlap; the marked slots' records are parked in LDS, indexed by
   // their position in the window, and read back as broadcasts
-  __shared__ WinRec wrec_all[(kBlock / LPR) * WIN];
-  WinRec* wrec = wrec_all + (threadIdx.x / LPR) * WIN;
+  WinRec* wrec = reinterpret_cast<WinRec*>(lds_raw) + (threadIdx.x / LPR) * WIN;
   {
     SlotRec sr[PLANES];
     double ee[PLANES];
@@ -689,10 +815,7 @@ struct FinArgs {
   const int32_t* carry_idx;
   const double* carries;
   double stamp;
-  const int32_t* hot_cols;
-  int32_t n_hot;
-  const double* hot_slab;
-  int32_t n_slabs;
+  int32_t n_slabs;            // forward workgroups of this step
   const double* err_partial;  // [n_slabs] per-workgroup sums of the residual
   int32_t k;
   int64_t n;
@@ -703,91 +826,9 @@ struct FinArgs {
   double* grad;  // nullable
 };
 
-// tot[f] = sum_{r<rows} base[r*width + f], f < width, rows contiguous, in a
-// fixed order: the block's threads split into row groups x factor lanes, each
-// group sums its rows in ascending order (16 loads in flight), the groups are
-// then added in group order.
-__device__ inline void ordered_rows_sum(const double* base, int rows, int width,
-                                        double* scratch /*[kBlock]*/, double* tot /*[width]*/) {
-  constexpr int U = 16;
-  const int fw = width < kBlock ? width : kBlock;  // factor lanes per row group
-  const int nsg = kBlock / fw;
-  const int sg = threadIdx.x / fw, fl = threadIdx.x % fw;
-  const bool live = sg < nsg;
-  for (int f0 = 0; f0 < width; f0 += fw) {
-    const int f = f0 + fl;
-    double acc = 0.0;
-    if (live && f < width) {
-      for (int r = sg; r < rows; r += nsg * U) {
-        double v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int rr = r + u * nsg;
-          v[u] = base[int64_t(rr < rows ? rr : r) * width + f];
-          if (rr >= rows) v[u] = 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc += v[u];
-      }
-    }
-    __syncthreads();
-    scratch[threadIdx.x] = acc;
-    __syncthreads();
-    if (sg == 0 && f < width) {
-      double s = 0.0;
-      for (int j = 0; j < nsg; ++j) s += scratch[j * fw + fl];
-      tot[f] = s;
-    }
-  }
-  __syncthreads();
-}
-
-// Same for the stamped carry rows of one long crossing column: row r is
-// carries[idx[r]], valid iff its stamp is this step's.
-__device__ inline void ordered_carry_sum(const double* carries, const int32_t* idx, int rows,
-                                         int k, double stamp, double* scratch, double* tot) {
-  constexpr int U = 8;
-  const int width = k + 2;
-  const int fw = width < kBlock ? width : kBlock;
-  const int nsg = kBlock / fw;
-  const int sg = threadIdx.x / fw, fl = threadIdx.x % fw;
-  const bool live = sg < nsg;
-  for (int f0 = 0; f0 < width; f0 += fw) {
-    const int f = f0 + fl;
-    double acc = 0.0;
-    if (live && f < width) {
-      for (int r = sg; r < rows; r += nsg * U) {
-        const double* row[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int rr = r + u * nsg;
-          row[u] = carries + int64_t(idx[rr < rows ? rr : r]) * (k + 3);
-        }
-        double v[U], st[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          v[u] = row[u][f];
-          st[u] = row[u][k + 2];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc += (r + u * nsg < rows && st[u] == stamp) ? v[u] : 0.0;
-      }
-    }
-    __syncthreads();
-    scratch[threadIdx.x] = acc;
-    __syncthreads();
-    if (sg == 0 && f < width) {
-      double s = 0.0;
-      for (int j = 0; j < nsg; ++j) s += scratch[j * fw + fl];
-      tot[f] = s;
-    }
-  }
-  __syncthreads();
-}
-
 // blocks [0, nb_cross): short crossing columns, one per lane group; then one block
-// per long crossing column; then one block per hot column; last block: w0 from the
-// forward workgroups' residual sums.
+// per long crossing column; last block: w0 from the forward workgroups' residual
+// sums.  (Hot columns are reduced by extra workgroups of fm_consume_kernel.)
 template <int LPR, int VEC, int NC>
 __global__ __launch_bounds__(kBlock) void fm_finalize_kernel(FinArgs a, int nb_cross) {
   __shared__ double scratch[kBlock];
@@ -846,19 +887,12 @@ __global__ __launch_bounds__(kBlock) void fm_finalize_kernel(FinArgs a, int nb_c
     if (any) apply_column<LPR, VEC, NC>(acc, vold, cc.col, a.V, a.w, a.grad, a.n, k, a.lr, l);
     return;
   }
-  const int hb = b - nb_cross - a.n_cross_long;
-  if (hb < a.n_hot) {
-    int32_t col;
-    if (hb < 0) {
-      const CrossCol cc = a.cross[a.n_cross_short + (b - nb_cross)];
-      col = cc.col;
-      ordered_carry_sum(a.carries, a.carry_idx + cc.idx_begin, cc.idx_count, k, a.stamp, scratch,
-                        tot);
-    } else {
-      col = a.hot_cols[hb];
-      ordered_rows_sum(a.hot_slab + int64_t(hb) * a.n_slabs * (k + 2), a.n_slabs, k + 2, scratch,
-                       tot);
-    }
+  const int lb = b - nb_cross;
+  if (lb < a.n_cross_long) {
+    const CrossCol cc = a.cross[a.n_cross_short + lb];
+    const int32_t col = cc.col;
+    ordered_carry_sum(a.carries, a.carry_idx + cc.idx_begin, cc.idx_count, k, a.stamp, scratch,
+                      tot);
     const double gw = tot[k], d = tot[k + 1];
     for (int f = threadIdx.x; f < k; f += kBlock) {
       const int64_t at = int64_t(col) * k + f;

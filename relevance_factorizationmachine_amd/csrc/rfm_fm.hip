@@ -56,7 +56,7 @@ namespace rfm {
 // bytes of LDS a forward workgroup spends on the hot class sums: with the 4 KiB of
 // reduction scratch and the 16.5 KiB entry buffer, two 512-thread workgroups fit a CU
 constexpr size_t kHotLdsBudget = 56 << 10;
-constexpr int kMaxHot = 1024;
+constexpr int kMaxHot = 160;  // beyond this the slab traffic outweighs what the class saves
 
 // ---------------------------------------------------------------------------
 // dispatch on the factor count
@@ -460,7 +460,7 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
       const size_t per_col = size_t(n_factors + 2) * 8;
       // RFM_HOT_LDS_KB overrides the LDS budget (tuning experiments only)
       const size_t budget = size_t(env_int("RFM_HOT_LDS_KB", int(kHotLdsBudget >> 10))) << 10;
-      const size_t cap = std::min<size_t>(kMaxHot, budget / per_col);
+      const size_t cap = std::min<size_t>(size_t(env_int("RFM_MAX_HOT", kMaxHot)), budget / per_col);
       if (hot_cols.size() > cap) hot_cols.resize(cap);
       std::sort(hot_cols.begin(), hot_cols.end());
       for (size_t h = 0; h < hot_cols.size(); ++h) hot_rank[size_t(hot_cols[h])] = int32_t(h);

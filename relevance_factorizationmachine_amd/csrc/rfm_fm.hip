@@ -206,11 +206,11 @@ struct rfm_fm_plan {
   int32_t n_win = 0, n_cross_short = 0, n_cross_long = 0, n_hot = 0;
   int64_t step = 0;  // stamps the carries of a step
   rfm::DevBuf ent, rows, slot_t, slots, win, cross, carry_idx, carries, Q, err, hot_cols,
-      hot_slab, err_partial;
+      hot_slab, hot_part, err_partial;
   size_t device_bytes() const {
     return ent.bytes + rows.bytes + slot_t.bytes + slots.bytes + win.bytes + cross.bytes +
            carry_idx.bytes + carries.bytes + Q.bytes + err.bytes + hot_cols.bytes +
-           hot_slab.bytes + err_partial.bytes;
+           hot_slab.bytes + hot_part.bytes + err_partial.bytes;
   }
 };
 
@@ -299,11 +299,11 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
     c.grad = d_grad;
     const int wpb = (kBlock / kWave) * (kWave / s.lpr);  // one window per lane group
     c.nb_win = (plan->n_win + wpb - 1) / wpb;
-    c.hot_cols = plan->hot_cols.as<int32_t>();
     c.n_hot = plan->n_hot;
     c.hot_slab = plan->hot_slab.as<double>();
     c.n_slabs = geom.grid;
-    const int grid = c.nb_win + plan->n_hot;  // windows, then one workgroup per hot column
+    c.hot_part = plan->hot_part.as<double>();
+    const int grid = c.nb_win + plan->n_hot * kHotParts;  // windows, then the hot columns' parts
 #ifdef RFM_ABLATE
     if (!(f.ablate & 128))
 #endif
@@ -323,6 +323,9 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   fa.carry_idx = plan->carry_idx.as<int32_t>();
   fa.carries = plan->carries.as<double>();
   fa.stamp = stamp;
+  fa.hot_cols = plan->hot_cols.as<int32_t>();
+  fa.n_hot = plan->n_hot;
+  fa.hot_part = plan->hot_part.as<double>();
   fa.n_slabs = geom.grid;
   fa.err_partial = plan->err_partial.as<double>();
   fa.k = k;
@@ -334,7 +337,7 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   fa.grad = d_grad;
   {
     const int gpb = kBlock / s.lpr;
-    const int nb_cross = (plan->n_cross_short + gpb - 1) / gpb;
+    const int nb_cross = (plan->n_hot + plan->n_cross_short + gpb - 1) / gpb;
     const int grid = nb_cross + plan->n_cross_long + 1;
 #ifdef RFM_ABLATE
     if (f.ablate & 256) return;
@@ -553,6 +556,7 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
     RFM_HIP_CHECK(hipMemsetAsync(plan->carries.p, 0, plan->carries.bytes, ctx->stream));
     plan->hot_slab.alloc(size_t(kMaxFwdGrid) * std::max<size_t>(hot_cols.size(), 1) *
                          size_t(n_factors + 2) * 8);
+    plan->hot_part.alloc(std::max<size_t>(hot_cols.size(), 1) * kHotParts * size_t(n_factors + 2) * 8);
     plan->err_partial.alloc(size_t(kMaxFwdGrid) * 8);
     plan->Q.alloc(size_t(max_batch) * size_t(n_factors) * 8);
     plan->err.alloc(size_t(max_batch) * 8);

@@ -514,27 +514,18 @@ __device__ inline void ordered_carry_sum(const double* carries, const int32_t* i
   __syncthreads();
 }
 
-// One hot column: its slabs (one per forward workgroup) summed in block order,
-// then V[col,:], w[col] updated (or the gradient row written).  Whole workgroup.
-__device__ inline void hot_column_block(int h, const int32_t* hot_cols, const double* hot_slab,
-                                        int n_slabs, int k, int64_t n, double* V, double* w,
-                                        double lr, double* grad, double* scratch, double* tot) {
-  const int32_t col = hot_cols[h];
-  ordered_rows_sum(hot_slab + int64_t(h) * n_slabs * (k + 2), n_slabs, k + 2, scratch, tot);
-  const double gw = tot[k], d = tot[k + 1];
-  for (int f = threadIdx.x; f < k; f += kBlock) {
-    const int64_t at = int64_t(col) * k + f;
-    if (grad)
-      grad[at] = d * V[at] - tot[f];
-    else
-      V[at] += lr * (tot[f] - d * V[at]);
-  }
-  if (threadIdx.x == 0) {
-    if (grad)
-      grad[n * k + col] = -gw;
-    else
-      w[col] += lr * gw;
-  }
+// slab ranges a hot column's reduction is cut into (one workgroup each)
+constexpr int kHotParts = 4;
+
+// Part `part` of hot column h: slabs [part*n/kHotParts, (part+1)*n/kHotParts) summed
+// in block order into hot_part[h][part][0..k+2).  Whole workgroup.
+__device__ inline void hot_part_block(int h, int part, const double* hot_slab, int n_slabs,
+                                      int k, double* hot_part, double* scratch, double* tot) {
+  const int lo = int(int64_t(part) * n_slabs / kHotParts);
+  const int hi = int(int64_t(part + 1) * n_slabs / kHotParts);
+  ordered_rows_sum(hot_slab + (int64_t(h) * n_slabs + lo) * (k + 2), hi - lo, k + 2, scratch, tot);
+  double* out = hot_part + (int64_t(h) * kHotParts + part) * (k + 2);
+  for (int f = threadIdx.x; f < k + 2; f += kBlock) out[f] = tot[f];
 }
 
 // ---------------------------------------------------------------------------
@@ -580,10 +571,10 @@ struct ConsArgs {
   // hot columns ride in the same launch: the workgroups after the windows reduce
   // the forward's slabs (independent of the sparse class, so the two overlap)
   int32_t nb_win;   // workgroups that process windows
-  const int32_t* hot_cols;
   int32_t n_hot;
   const double* hot_slab;
   int32_t n_slabs;
+  double* hot_part;  // [n_hot][kHotParts][k+2] partial sums out (fm_finalize_kernel adds them)
 };
 
 template <int VEC, int NC>
@@ -689,10 +680,11 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
   constexpr int kHotBytes = (kBlock + 1024 + 2) * int(sizeof(double));
   __shared__ double lds_raw[(kWrecBytes > kHotBytes ? kWrecBytes : kHotBytes) / 8];
   // the hot-column workgroups come last in the grid (measured: first, they delay
-  // the windows and the launch takes 4 us longer)
+  // the windows and the launch takes 4 us longer); kHotParts of them per column
   if (int(blockIdx.x) >= a.nb_win) {
-    hot_column_block(int(blockIdx.x) - a.nb_win, a.hot_cols, a.hot_slab, a.n_slabs, a.k, a.n, a.V,
-                     a.w, a.lr, a.grad, lds_raw, lds_raw + kBlock);
+    const int hb = int(blockIdx.x) - a.nb_win;
+    hot_part_block(hb / kHotParts, hb % kHotParts, a.hot_slab, a.n_slabs, a.k, a.hot_part, lds_raw,
+                   lds_raw + kBlock);
     return;
   }
   const int wblock = int(blockIdx.x);
@@ -815,6 +807,9 @@ struct FinArgs {
   const int32_t* carry_idx;
   const double* carries;
   double stamp;
+  const int32_t* hot_cols;    // hot columns: kHotParts partial rows each, from fm_consume_kernel
+  int32_t n_hot;
+  const double* hot_part;
   int32_t n_slabs;            // forward workgroups of this step
   const double* err_partial;  // [n_slabs] per-workgroup sums of the residual
   int32_t k;
@@ -826,9 +821,9 @@ struct FinArgs {
   double* grad;  // nullable
 };
 
-// blocks [0, nb_cross): short crossing columns, one per lane group; then one block
-// per long crossing column; last block: w0 from the forward workgroups' residual
-// sums.  (Hot columns are reduced by extra workgroups of fm_consume_kernel.)
+// blocks [0, nb_cross): hot columns (partial rows from fm_consume_kernel) and short
+// crossing columns, one per lane group; then one block per long crossing column;
+// last block: w0 from the forward workgroups' residual sums.
 template <int LPR, int VEC, int NC>
 __global__ __launch_bounds__(kBlock) void fm_finalize_kernel(FinArgs a, int nb_cross) {
   __shared__ double scratch[kBlock];
@@ -839,8 +834,35 @@ __global__ __launch_bounds__(kBlock) void fm_finalize_kernel(FinArgs a, int nb_c
     constexpr int GPB = kBlock / LPR;
     const int l = threadIdx.x % LPR;
     const int ci = b * GPB + threadIdx.x / LPR;
-    if (ci >= a.n_cross_short) return;
-    const CrossCol cc = a.cross[ci];
+    if (ci >= a.n_hot + a.n_cross_short) return;
+    if (ci < a.n_hot) {
+      // a hot column: its kHotParts partial rows, in part order
+      const int32_t col = a.hot_cols[ci];
+      const double* row = a.hot_part + int64_t(ci) * kHotParts * (k + 2);
+      ColAcc<VEC, NC> acc;
+      acc.clear();
+      Pack<VEC> vold[NC];
+#pragma unroll
+      for (int ch = 0; ch < NC; ++ch) {
+        const int f = (ch * LPR + l) * VEC;
+        vold[ch].load(a.V + int64_t(col) * k + (f < k ? f : 0));
+      }
+#pragma unroll
+      for (int p = 0; p < kHotParts; ++p) {
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+          const int f = (ch * LPR + l) * VEC;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc.m[ch][v] += row[p * (k + 2) + (f < k ? f : 0) + v];
+        }
+        acc.gw += row[p * (k + 2) + k];
+        acc.d += row[p * (k + 2) + k + 1];
+      }
+      apply_column<LPR, VEC, NC>(acc, vold, col, a.V, a.w, a.grad, a.n, k, a.lr, l);
+      return;
+    }
+    const CrossCol cc = a.cross[ci - a.n_hot];
+
     ColAcc<VEC, NC> acc;
     acc.clear();
     Pack<VEC> vold[NC];

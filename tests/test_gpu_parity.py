@@ -194,6 +194,35 @@ def test_fm_fit_ragged_logs(rfm, k, batch, dense_cols, hot):
     assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
 
 
+def test_non_canonical_csr_inputs(rfm):
+    """CSR as SciPy allows it: duplicate column entries inside a row (each stored
+    entry counts on its own, as in X.dot / X.power(2)), unsorted indices, explicitly
+    stored zeros, int64 index arrays."""
+    pkg = rfm[0]
+    rng = np.random.default_rng(11)
+    n_rows, n_cols, z = 700, 60, 9
+    indptr = np.arange(0, n_rows * z + 1, z, dtype=np.int64)
+    indices = rng.integers(0, n_cols, size=n_rows * z).astype(np.int64)  # duplicates, unsorted
+    data = rng.standard_normal(n_rows * z)
+    data[rng.integers(0, data.size, size=300)] = 0.0  # stored zeros
+    def log(m):
+        X = csr_matrix((data[: m * z].copy(), indices[: m * z].copy(), indptr[: m + 1].copy()), shape=(m, n_cols))
+        assert not X.has_canonical_format
+        return {"features": X, "labels": (rng.random(m) < 0.5).astype(np.int64),
+                "pscores": rng.uniform(0.1, 1.0, size=m) ** 0.5}
+    train, val = log(700), log(200)
+    kw = dict(n_epochs=5, n_factors=6, lr=1e-3, batch_size=256, seed=5)
+    for hot in (0, -1, 2):
+        model = _fm(pkg, n_features=n_cols, **kw)
+        model.hot_min_count = hot
+        tr, va = model.fit(train, val)
+        ref = cpu_ref.fm_fit(train, val, **kw)
+        assert rel_err(model.V(), ref["V"]) < TIGHT and rel_err(model.w(), ref["w"]) < TIGHT
+        assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
+        assert rel_err(model.predict(val["features"]),
+                       cpu_ref.fm_predict(val["features"], ref["w0"], ref["w"], ref["V"])) < TIGHT
+
+
 def test_saturated_logits_and_empty_inputs(rfm):
     """_sigmoid clips at +-700 (fixture G9); rows without entries score sigmoid(w0)."""
     pkg = rfm[0]

@@ -17,6 +17,9 @@
  *    ctx-/plan-owned scratch and frees it in the matching destroy call.
  *  - calls that take a ctx are asynchronous on the ctx's HIP stream; use
  *    rfm_sync() (or synchronise the stream yourself) before reading results.
+ *  - a CSR row names a column at most once (SciPy sums duplicate entries before
+ *    it squares them, src/fm.py:127; the Python mirror canonicalises its inputs the
+ *    same way); the order of a row's entries is free, explicit zeros are fine.
  *  - all parameters and activations are float64 (the reference computes in
  *    NumPy float64); CSR column indices and row ids are int32, CSR row
  *    pointers int64, labels are passed as float64 {0,1}.
@@ -207,6 +210,29 @@ int32_t rfm_mf_sgd_levels(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d
                           int32_t n_levels, double* d_P,
                           double* d_Q, double* d_bu, double* d_bi, double b,
                           int32_t n_factors, double lr, double reg);
+
+/* The same schedule in the form the fast kernels read: the batch's examples as
+ * 24-byte records {int32 user, int32 item, int32 cache_slot, int32 early, double
+ * label/propensity} grouped by level (ascending batch position inside a level).
+ * h_users/h_items/h_y/h_pscore are the batch in batch order.  Up to cache_cap items
+ * that occur more than once in the batch (most frequent first) are listed in
+ * h_cache_items: the sequential kernel keeps their rows in LDS (cache_slot >= 0;
+ * -1 = the item occurs once, -2 = repeated without a slot); early = 1 when the
+ * user row's previous writer lies at least three levels back, so the row may be
+ * fetched ahead.  Capacities: h_ex batch records, h_level_ptr batch+1,
+ * h_cache_items cache_cap. */
+int32_t rfm_mf_schedule_ex(const int32_t* h_users, const int32_t* h_items, const double* h_y,
+                           const double* h_pscore, int64_t batch, int32_t n_users,
+                           int32_t n_items, int32_t cache_cap, void* h_ex,
+                           int32_t* h_level_ptr, int32_t* h_n_levels, int32_t* h_cache_items,
+                           int32_t* h_n_cached);
+/* rfm_mf_sgd_levels on those records (d_ex = device copy of h_ex, d_cache_items of
+ * h_cache_items; n_cached rows of n_factors+2 doubles must fit 64 KiB of LDS). */
+int32_t rfm_mf_sgd_levels_ex(rfm_ctx* ctx, const void* d_ex, const int32_t* h_level_ptr,
+                             const int32_t* d_level_ptr, int32_t n_levels,
+                             const int32_t* d_cache_items, int32_t n_cached, double* d_P,
+                             double* d_Q, double* d_bu, double* d_bi, double b,
+                             int32_t n_factors, double lr, double reg);
 
 /* ---- multi-GPU exchange (RCCL over xGMI) ----------------------------------
  * The data-parallel FM step all-reduces the dense gradient buffer of rfm_fm_grad

@@ -444,12 +444,22 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
     const size_t nf = static_cast<size_t>(n_features);
     const size_t nr = static_cast<size_t>(n_rows);
 
-    // column lengths
+    // column lengths; a row must not name a column twice (SciPy sums such duplicates
+    // before squaring -- the caller canonicalises, as the Python mirror does)
     std::vector<int64_t> len(nf, 0);
-    for (int64_t p = 0; p < nnz; ++p) {
-      const int32_t c = h_indices[p];
-      RFM_REQUIRE(c >= 0 && c < n_features, "column index %d out of range", c);
-      len[size_t(c)]++;
+    {
+      std::vector<int64_t> seen_in_row(nf, -1);
+      for (int64_t r = 0; r < n_rows; ++r)
+        for (int64_t p = h_indptr[r]; p < h_indptr[r + 1]; ++p) {
+          RFM_REQUIRE(p >= 0 && p < nnz, "indptr out of range at row %lld", (long long)r);
+          const int32_t c = h_indices[p];
+          RFM_REQUIRE(c >= 0 && c < n_features, "column index %d out of range", c);
+          RFM_REQUIRE(seen_in_row[size_t(c)] != r,
+                      "row %lld names column %d twice: sum duplicate entries first", (long long)r,
+                      c);
+          seen_in_row[size_t(c)] = r;
+          len[size_t(c)]++;
+        }
     }
     // hot class: expected entries per batch >= hot_min, most frequent first, LDS budget
     std::vector<int32_t> hot_cols;

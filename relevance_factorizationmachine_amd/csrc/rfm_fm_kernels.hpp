@@ -32,10 +32,25 @@ struct RowRec {      // one row of the training log, 32 B
 // ---------------------------------------------------------------------------
 // helpers
 // ---------------------------------------------------------------------------
+// Sum over the LPR lanes of a lane group; every lane gets the total.  The steps
+// inside a row of 16 lanes are DPP moves (quad permutes, half-row and row mirrors:
+// a few cycles each) instead of ds_bpermute round trips through the LDS crossbar.
+template <int CTRL>
+__device__ inline double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
 template <int LPR>
 __device__ inline double group_sum(double v) {
-#pragma unroll
-  for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, LPR);
+  if (LPR >= 2) v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  if (LPR >= 4) v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  if (LPR >= 8) v += dpp_move<0x141>(v);  // row_half_mirror
+  if (LPR >= 16) v += dpp_move<0x140>(v); // row_mirror
+  if (LPR >= 32) v += __shfl_xor(v, 16, 64);
+  if (LPR >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
 

@@ -177,4 +177,92 @@ int32_t rfm_mf_schedule(const int32_t* h_users, const int32_t* h_items, int64_t 
   });
 }
 
+// the level-ordered record of rfm_mf.hip (MfEx)
+struct HostMfEx {
+  int32_t u, i, cslot, early;
+  double ry;
+};
+
+int32_t rfm_mf_schedule_ex(const int32_t* h_users, const int32_t* h_items, const double* h_y,
+                           const double* h_pscore, int64_t batch, int32_t n_users,
+                           int32_t n_items, int32_t cache_cap, void* h_ex,
+                           int32_t* h_level_ptr, int32_t* h_n_levels, int32_t* h_cache_items,
+                           int32_t* h_n_cached) {
+  return guarded([&] {
+    RFM_REQUIRE(h_users && h_items && h_y && h_pscore && h_ex && h_level_ptr && h_n_levels &&
+                    h_cache_items && h_n_cached,
+                "null pointer");
+    RFM_REQUIRE(batch >= 0 && batch < (int64_t(1) << 31) && cache_cap >= 0, "bad shape");
+    static thread_local std::vector<int32_t> last_u, last_i, cnt_i, slot_i;
+    if (int64_t(last_u.size()) < n_users) last_u.assign(size_t(n_users), -1);
+    if (int64_t(last_i.size()) < n_items) {
+      last_i.assign(size_t(n_items), -1);
+      cnt_i.assign(size_t(n_items), 0);
+      slot_i.assign(size_t(n_items), -1);
+    }
+    std::vector<int32_t> level(static_cast<size_t>(batch), 0), early(static_cast<size_t>(batch), 0);
+    int32_t n_levels = 0;
+    bool bad = false;
+    for (int64_t s = 0; s < batch; ++s) {
+      const int32_t u = h_users[s], i = h_items[s];
+      if (u < 0 || u >= n_users || i < 0 || i >= n_items) {
+        bad = true;
+        break;
+      }
+      const int32_t lv = std::max(last_u[u], last_i[i]) + 1;
+      level[size_t(s)] = lv;
+      // the user row is final three levels before lv (or was never written in this batch)
+      early[size_t(s)] = (last_u[u] < 0 || lv - last_u[u] >= 3) ? 1 : 0;
+      last_u[u] = lv;
+      last_i[i] = lv;
+      cnt_i[i]++;
+      n_levels = std::max(n_levels, lv + 1);
+    }
+    // items that occur more than once, most frequent first, get the LDS slots
+    std::vector<int32_t> repeated;
+    if (!bad)
+      for (int64_t s = 0; s < batch; ++s) {
+        const int32_t i = h_items[s];
+        if (cnt_i[i] >= 2 && slot_i[i] == -1) {
+          slot_i[i] = -2;  // seen
+          repeated.push_back(i);
+        }
+      }
+    std::stable_sort(repeated.begin(), repeated.end(),
+                     [&](int32_t x, int32_t y) { return cnt_i[x] > cnt_i[y]; });
+    const int32_t n_cached = int32_t(std::min<size_t>(repeated.size(), size_t(cache_cap)));
+    for (int32_t c = 0; c < n_cached; ++c) {
+      slot_i[repeated[size_t(c)]] = c;
+      h_cache_items[c] = repeated[size_t(c)];
+    }
+    // level-ordered records (stable: ascending batch position inside a level)
+    std::vector<int32_t> cnt(static_cast<size_t>(n_levels) + 1, 0);
+    if (!bad) {
+      for (int64_t s = 0; s < batch; ++s) cnt[size_t(level[size_t(s)]) + 1]++;
+      for (int32_t l = 0; l < n_levels; ++l) cnt[size_t(l) + 1] += cnt[size_t(l)];
+      for (int32_t l = 0; l <= n_levels; ++l) h_level_ptr[l] = cnt[size_t(l)];
+      HostMfEx* ex = static_cast<HostMfEx*>(h_ex);
+      for (int64_t s = 0; s < batch; ++s) {
+        const int32_t i = h_items[s];
+        const int32_t cs = cnt_i[i] >= 2 ? slot_i[i] : -1;  // -2: repeated, no slot
+        ex[cnt[size_t(level[size_t(s)])]++] =
+            HostMfEx{h_users[s], i, cs, early[size_t(s)], h_y[s] / h_pscore[s]};
+      }
+    }
+    // reset only what this batch touched
+    for (int64_t s = 0; s < batch; ++s) {
+      const int32_t u = h_users[s], i = h_items[s];
+      if (u >= 0 && u < n_users) last_u[u] = -1;
+      if (i >= 0 && i < n_items) {
+        last_i[i] = -1;
+        cnt_i[i] = 0;
+        slot_i[i] = -1;
+      }
+    }
+    RFM_REQUIRE(!bad, "user/item id out of range");
+    *h_n_levels = n_levels;
+    *h_n_cached = n_cached;
+  });
+}
+
 }  // extern "C"

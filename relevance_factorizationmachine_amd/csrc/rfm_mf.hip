@@ -22,10 +22,25 @@ constexpr int kMfBlock = 256;
 constexpr int kSeqBlock = 1024;
 constexpr double kMfLogitClip = 700.0;  // src/base.py:65
 
+// Sum over the LPR lanes of a lane group; every lane gets the total.  The steps
+// inside a row of 16 lanes are DPP moves (quad permutes, half-row and row mirrors:
+// a few cycles each) instead of ds_bpermute round trips through the LDS crossbar.
+template <int CTRL>
+__device__ inline double mf_dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
 template <int LPR>
 __device__ inline double mf_group_sum(double v) {
-#pragma unroll
-  for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, LPR);
+  if (LPR >= 2) v += mf_dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  if (LPR >= 4) v += mf_dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  if (LPR >= 8) v += mf_dpp_move<0x141>(v);  // row_half_mirror
+  if (LPR >= 16) v += mf_dpp_move<0x140>(v); // row_mirror
+  if (LPR >= 32) v += __shfl_xor(v, 16, 64);
+  if (LPR >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
 
@@ -234,6 +249,238 @@ __global__ __launch_bounds__(kSeqBlock) void mf_sgd_seq_kernel(MfSgdArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// level-ordered example records: the fast form of the same schedule
+// ---------------------------------------------------------------------------
+struct MfEx {       // one example of a batch, stored in level order, 24 B
+  int32_t u, i;     // user, item
+  int32_t cslot;    // >= 0: LDS cache slot of the item row in the sequential kernel;
+                    // -1: the item occurs once in the batch; -2: repeated but not cached
+  int32_t early;    // 1: the user row is final three levels before this example runs
+  double ry;        // label / propensity
+};
+
+struct MfExArgs {
+  const MfEx* ex;            // [batch], grouped by level
+  const int32_t* level_ptr;  // device copy (sequential kernel only)
+  int32_t lo, hi;            // wide kernel: ex[lo, hi); seq kernel: levels [lo, hi)
+  const int32_t* cache_items;  // items whose rows the sequential kernel keeps in LDS
+  int32_t n_cached;
+  double* P;
+  double* Q;
+  double* bu;
+  double* bi;
+  double b;
+  int32_t k;
+  double lr, reg;
+};
+
+// the arithmetic of one example on rows already in registers (src/mf.py:99-108,
+// 172-216): returns the residual, rows and biases are updated in place
+template <int LPR, int VEC, int NC>
+__device__ inline void mf_update(MfPack<VEC> (&pp)[NC], MfPack<VEC> (&pq)[NC], double& bu,
+                                 double& bi, double ry, double b, double lr, double reg, int k,
+                                 int l) {
+  double dot = 0.0;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int f = (c * LPR + l) * VEC;
+    if (f < k) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) dot += pp[c].v[v] * pq[c].v[v];
+    }
+  }
+  dot = mf_group_sum<LPR>(dot);
+  const double err = ry - mf_sigmoid(dot + bu + bi + b);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const double p_new = pp[c].v[v] - lr * (-err * pq[c].v[v] + reg * pp[c].v[v]);
+      // the item row sees the user row this example has just updated (src/mf.py:193)
+      const double q_new = pq[c].v[v] - lr * (-err * p_new + reg * pq[c].v[v]);
+      pp[c].v[v] = p_new;
+      pq[c].v[v] = q_new;
+    }
+  }
+  bu = bu - lr * (-err + reg * bu);
+  bi = bi - lr * (-err + reg * bi);
+}
+
+template <int LPR, int VEC, int NC>
+__device__ inline void mf_load_row(MfPack<VEC> (&dst)[NC], const double* row, int k, int l) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int f = (c * LPR + l) * VEC;
+    dst[c].load(row + (f < k ? f : 0));
+  }
+}
+
+template <int LPR, int VEC, int NC>
+__device__ inline void mf_store_row(const MfPack<VEC> (&src)[NC], double* row, int k, int l) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int f = (c * LPR + l) * VEC;
+    if (f < k) src[c].store(row + f);
+  }
+}
+
+// one level, many workgroups (examples of a level touch disjoint rows)
+template <int LPR, int VEC, int NC>
+__global__ __launch_bounds__(kMfBlock) void mf_sgd_wide_ex_kernel(MfExArgs a) {
+  constexpr int GPB = kMfBlock / LPR;
+  const int l = threadIdx.x % LPR;
+  const int g = threadIdx.x / LPR;
+  const int k = a.k;
+  for (int64_t idx = int64_t(a.lo) + int64_t(blockIdx.x) * GPB + g; idx < a.hi;
+       idx += int64_t(gridDim.x) * GPB) {
+    const MfEx e = a.ex[idx];
+    MfPack<VEC> pp[NC], pq[NC];
+    mf_load_row<LPR, VEC, NC>(pp, a.P + int64_t(e.u) * k, k, l);
+    mf_load_row<LPR, VEC, NC>(pq, a.Q + int64_t(e.i) * k, k, l);
+    double bu = a.bu[e.u], bi = a.bi[e.i];
+    mf_update<LPR, VEC, NC>(pp, pq, bu, bi, e.ry, a.b, a.lr, a.reg, k, l);
+    mf_store_row<LPR, VEC, NC>(pp, a.P + int64_t(e.u) * k, k, l);
+    mf_store_row<LPR, VEC, NC>(pq, a.Q + int64_t(e.i) * k, k, l);
+    if (l == 0) {
+      a.bu[e.u] = bu;
+      a.bi[e.i] = bi;
+    }
+  }
+}
+
+// rows of one example held in registers ahead of its level
+template <int VEC, int NC>
+struct MfRegs {
+  MfPack<VEC> pp[NC], pq[NC];
+  double bu, bi;
+  bool got_user;  // pp / bu are loaded (and final)
+};
+
+// the example lane group g runs at level `lev` (false: none)
+__device__ __forceinline__ bool mf_fetch_ex(const MfExArgs& a, int lev, int g, MfEx& e) {
+  if (lev >= a.hi) return false;
+  const int32_t idx = a.level_ptr[lev] + g;
+  if (idx >= a.level_ptr[lev + 1]) return false;
+  e = a.ex[idx];
+  return true;
+}
+
+// what may be read ahead of the example's level: the user row if final by now,
+// the item row if it is not one of the LDS-cached ones (then it occurs once)
+template <int LPR, int VEC, int NC>
+__device__ __forceinline__ void mf_fetch_rows(const MfExArgs& a, const MfEx& e, bool user_final,
+                                              MfRegs<VEC, NC>& r, int l) {
+  const int k = a.k;
+  r.got_user = user_final;
+  if (user_final) {
+    mf_load_row<LPR, VEC, NC>(r.pp, a.P + int64_t(e.u) * k, k, l);
+    r.bu = a.bu[e.u];
+  }
+  if (e.cslot == -1) {
+    mf_load_row<LPR, VEC, NC>(r.pq, a.Q + int64_t(e.i) * k, k, l);
+    r.bi = a.bi[e.i];
+  }
+}
+
+// Levels [lo, hi), each of at most kSeqBlock/LPR examples, by ONE workgroup with a
+// barrier between levels.  What makes a level short (the chain through a popular
+// item is hundreds of levels long):
+//  * the rows (and biases) of the items that occur more than once in the batch
+//    live in LDS for the whole launch, so the chain never goes through L2;
+//  * a lane group knows the examples it will run up to three levels ahead and
+//    fetches an example's user row, user bias and (uncached) item row two levels
+//    before it runs, whenever the user row is final by then (MfEx.early: its
+//    previous writer is at least three levels back; an uncached item occurs once
+//    in the batch, so its row is always final).
+template <int LPR, int VEC, int NC>
+__global__ __launch_bounds__(kSeqBlock) void mf_sgd_seq_ex_kernel(MfExArgs a) {
+  extern __shared__ double qcache[];  // [n_cached][k+2]: item row, item bias, pad
+  const int l = threadIdx.x % LPR;
+  const int g = threadIdx.x / LPR;
+  const int k = a.k;
+  const int cw = k + 2;
+  for (int i = threadIdx.x; i < a.n_cached * cw; i += kSeqBlock) {
+    const int c = i / cw, f = i % cw;
+    const int32_t item = a.cache_items[c];
+    qcache[i] = f < k ? a.Q[int64_t(item) * k + f] : (f == k ? a.bi[item] : 0.0);
+  }
+
+  // pipeline per lane group: A runs at this level, B at the next, C the one after.
+  // Rows are held ahead in registers only for factor counts that leave room (NC <= 2);
+  // wider rows are read when their level starts.
+  constexpr bool PF = NC <= 2;
+  MfEx eA{}, eB{}, eC{};
+  MfRegs<VEC, NC> rA, rB, rC;
+  rA.got_user = rB.got_user = rC.got_user = false;
+  bool hA = mf_fetch_ex(a, a.lo, g, eA);
+  bool hB = mf_fetch_ex(a, a.lo + 1, g, eB);
+  bool hC = mf_fetch_ex(a, a.lo + 2, g, eC);
+  // every level before lo has run: A's rows are final; B's only if marked early
+  if (PF && hA) mf_fetch_rows<LPR, VEC, NC>(a, eA, true, rA, l);
+  if (PF && hB) mf_fetch_rows<LPR, VEC, NC>(a, eB, eB.early != 0, rB, l);
+  __syncthreads();
+
+  for (int lev = a.lo; lev < a.hi; ++lev) {
+    MfEx eD{};
+    const bool hD = mf_fetch_ex(a, lev + 3, g, eD);
+    if (PF && hC) mf_fetch_rows<LPR, VEC, NC>(a, eC, eC.early != 0, rC, l);
+    if (hA) {
+      if (!PF || !rA.got_user) {  // written one or two levels ago: read it now
+        mf_load_row<LPR, VEC, NC>(rA.pp, a.P + int64_t(eA.u) * k, k, l);
+        rA.bu = a.bu[eA.u];
+      }
+      if (eA.cslot == -2 || (!PF && eA.cslot == -1)) {  // item row through memory
+        mf_load_row<LPR, VEC, NC>(rA.pq, a.Q + int64_t(eA.i) * k, k, l);
+        rA.bi = a.bi[eA.i];
+      }
+      double* crow = qcache + (eA.cslot >= 0 ? eA.cslot : 0) * cw;
+      if (eA.cslot >= 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int f = (c * LPR + l) * VEC;
+          rA.pq[c].load(crow + (f < k ? f : 0));
+        }
+        rA.bi = crow[k];
+      }
+      mf_update<LPR, VEC, NC>(rA.pp, rA.pq, rA.bu, rA.bi, eA.ry, a.b, a.lr, a.reg, k, l);
+      mf_store_row<LPR, VEC, NC>(rA.pp, a.P + int64_t(eA.u) * k, k, l);
+      if (l == 0) a.bu[eA.u] = rA.bu;
+      if (eA.cslot >= 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int f = (c * LPR + l) * VEC;
+          if (f < k) rA.pq[c].store(crow + f);
+        }
+        if (l == 0) crow[k] = rA.bi;
+      } else {
+        mf_store_row<LPR, VEC, NC>(rA.pq, a.Q + int64_t(eA.i) * k, k, l);
+        if (l == 0) a.bi[eA.i] = rA.bi;
+      }
+    }
+    __syncthreads();
+    eA = eB;
+    hA = hB;
+    eB = eC;
+    hB = hC;
+    eC = eD;
+    hC = hD;
+    if (PF) {
+      rA = rB;
+      rB = rC;
+    }
+  }
+  // write the cached item rows back
+  for (int i = threadIdx.x; i < a.n_cached * cw; i += kSeqBlock) {
+    const int c = i / cw, f = i % cw;
+    const int32_t item = a.cache_items[c];
+    if (f < k)
+      a.Q[int64_t(item) * k + f] = qcache[i];
+    else if (f == k)
+      a.bi[item] = qcache[i];
+  }
+}
+
 struct MfShape {
   int lpr, vec, nc;
 };
@@ -420,6 +667,66 @@ int32_t rfm_mf_sgd_levels(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d
   hipLaunchKernelGGL((mf_sgd_seq_kernel<L, Vv, N>), dim3(1), dim3(kSeqBlock), 0, ctx->stream, a)
         RFM_MF_FOR_SHAPE(s, RFM_CALL_SEQ);
 #undef RFM_CALL_SEQ
+        lev = end;
+      }
+    }
+    RFM_HIP_CHECK(hipGetLastError());
+  });
+}
+
+int32_t rfm_mf_sgd_levels_ex(rfm_ctx* ctx, const void* d_ex, const int32_t* h_level_ptr,
+                             const int32_t* d_level_ptr, int32_t n_levels,
+                             const int32_t* d_cache_items, int32_t n_cached, double* d_P,
+                             double* d_Q, double* d_bu, double* d_bi, double b,
+                             int32_t n_factors, double lr, double reg) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx && d_ex && h_level_ptr && d_level_ptr && d_P && d_Q && d_bu && d_bi,
+                "null pointer");
+    RFM_REQUIRE(n_levels >= 0 && n_cached >= 0 && (n_cached == 0 || d_cache_items),
+                "bad schedule");
+    const MfShape s = mf_shape_for(n_factors);
+    const size_t lds = size_t(n_cached) * size_t(n_factors + 2) * sizeof(double);
+    RFM_REQUIRE(lds <= (64u << 10), "item cache of %d rows does not fit LDS", n_cached);
+    MfExArgs a{};
+    a.ex = static_cast<const MfEx*>(d_ex);
+    a.level_ptr = d_level_ptr;
+    a.cache_items = d_cache_items;
+    a.n_cached = n_cached;
+    a.P = d_P;
+    a.Q = d_Q;
+    a.bu = d_bu;
+    a.bi = d_bi;
+    a.b = b;
+    a.k = n_factors;
+    a.lr = lr;
+    a.reg = reg;
+    // a level is "small" when the sequential workgroup covers it in one pass
+    const int seq_cap = kSeqBlock / s.lpr;
+    int lev = 0;
+    while (lev < n_levels) {
+      const int cnt = h_level_ptr[lev + 1] - h_level_ptr[lev];
+      RFM_REQUIRE(cnt >= 0, "level_ptr not monotone");
+      if (cnt > seq_cap) {
+        a.lo = h_level_ptr[lev];
+        a.hi = h_level_ptr[lev + 1];
+        const int gpb = kMfBlock / s.lpr;
+        const int grid = std::min((cnt + gpb - 1) / gpb, ctx->n_cu * 8);
+#define RFM_CALL_WIDE_EX(L, Vv, N)                                                            \
+  hipLaunchKernelGGL((mf_sgd_wide_ex_kernel<L, Vv, N>), dim3(grid), dim3(kMfBlock), 0,        \
+                     ctx->stream, a)
+        RFM_MF_FOR_SHAPE(s, RFM_CALL_WIDE_EX);
+#undef RFM_CALL_WIDE_EX
+        ++lev;
+      } else {
+        int end = lev;
+        while (end < n_levels && h_level_ptr[end + 1] - h_level_ptr[end] <= seq_cap) ++end;
+        a.lo = lev;
+        a.hi = end;
+#define RFM_CALL_SEQ_EX(L, Vv, N)                                                              \
+  hipLaunchKernelGGL((mf_sgd_seq_ex_kernel<L, Vv, N>), dim3(1), dim3(kSeqBlock), lds, ctx->stream, \
+                     a)
+        RFM_MF_FOR_SHAPE(s, RFM_CALL_SEQ_EX);
+#undef RFM_CALL_SEQ_EX
         lev = end;
       }
     }

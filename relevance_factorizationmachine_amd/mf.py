@@ -17,7 +17,7 @@ import numpy as np
 from . import _lib
 from .base import LOSS_EPS, PointwiseBaseRecommender
 from .optimizer import DeviceSGD
-from .runtime import Runtime, mf_schedule, sample_batches
+from .runtime import Runtime, mf_schedule_ex, sample_batches
 
 
 class DevicePairs:
@@ -107,6 +107,10 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
                   self.b_i.dev.data_ptr())
         b = float(self.b)
         keep = []  # device buffers of in-flight iterations
+        h_y = np.ascontiguousarray(train["labels"], dtype=np.float64)
+        h_p = np.ascontiguousarray(train["pscores"], dtype=np.float64)
+        # item rows the sequential kernel may keep in LDS (48 KiB of rows + bias)
+        cache_cap = int(min(1024, (48 << 10) // ((self.n_factors + 2) * 8)))
 
         for epoch in range(self.n_epochs):
             rows = ids[epoch]
@@ -117,14 +121,17 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
                     ids_ptr, self.batch_size, *params, b, self.n_factors, float(self.lr),
                     float(self.reg)))
             else:
-                order, level_ptr = mf_schedule(tr.h_users[rows], tr.h_items[rows], self.n_users,
-                                               self.n_items)
-                d_order, d_lptr = rt.upload(order), rt.upload(level_ptr)
-                keep.append((d_order, d_lptr))
-                _lib.check(rt.lib.rfm_mf_sgd_levels(
-                    rt.ctx, tr.users.data_ptr(), tr.items.data_ptr(), y.data_ptr(), p.data_ptr(),
-                    ids_ptr, d_order.data_ptr(), level_ptr.ctypes.data, d_lptr.data_ptr(),
-                    len(level_ptr) - 1, *params, b, self.n_factors, float(self.lr), float(self.reg)))
+                ex, level_ptr, cache_items = mf_schedule_ex(
+                    tr.h_users[rows], tr.h_items[rows], h_y[rows], h_p[rows], self.n_users,
+                    self.n_items, cache_cap)
+                d_ex = rt.upload(ex.view(np.uint8))
+                d_lptr = rt.upload(level_ptr)
+                d_cache = rt.upload(cache_items if cache_items.size else np.zeros(1, np.int32))
+                keep.append((d_ex, d_lptr, d_cache))
+                _lib.check(rt.lib.rfm_mf_sgd_levels_ex(
+                    rt.ctx, d_ex.data_ptr(), level_ptr.ctypes.data, d_lptr.data_ptr(),
+                    len(level_ptr) - 1, d_cache.data_ptr(), int(cache_items.size), *params, b,
+                    self.n_factors, float(self.lr), float(self.reg)))
             # train loss on the same batch with the updated parameters (src/mf.py:110-116)
             _lib.check(rt.lib.rfm_mf_predict_loss(
                 rt.ctx, tr.users.data_ptr(), tr.items.data_ptr(), y.data_ptr(), p.data_ptr(),

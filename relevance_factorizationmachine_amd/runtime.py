@@ -81,6 +81,12 @@ class DeviceCSR:
         from scipy import sparse
 
         X = X.tocsr() if not sparse.isspmatrix_csr(X) else X
+        if not X.has_canonical_format:
+            # SciPy's X.power(2) / X.multiply sum duplicate column entries of a row before
+            # squaring (src/fm.py:127 works on the de-duplicated matrix): do the same, on a
+            # copy -- the caller's matrix is never modified
+            X = X.copy()
+            X.sum_duplicates()
         self.shape: Tuple[int, int] = X.shape
         self.nnz = int(X.nnz)
         # host copies in the ABI's dtypes (kept for the plan builder)
@@ -143,3 +149,28 @@ def mf_schedule(users: np.ndarray, items: np.ndarray, n_users: int, n_items: int
     _lib.check(lib.rfm_mf_schedule(users.ctypes.data, items.ctypes.data, b, n_users, n_items,
                                    order.ctypes.data, level_ptr.ctypes.data, C.byref(n_levels)))
     return order, level_ptr[: n_levels.value + 1].copy()
+
+
+MF_EX_DTYPE = np.dtype([("u", np.int32), ("i", np.int32), ("cslot", np.int32), ("early", np.int32),
+                        ("ry", np.float64)])
+
+
+def mf_schedule_ex(users: np.ndarray, items: np.ndarray, y: np.ndarray, pscore: np.ndarray,
+                   n_users: int, n_items: int, cache_cap: int):
+    """Level schedule of one batch as level-ordered records:
+    ``(ex[B] (MF_EX_DTYPE), level_ptr int32[L+1], cache_items int32[n_cached])``."""
+    lib = _lib.load()
+    users = np.ascontiguousarray(users, dtype=np.int32)
+    items = np.ascontiguousarray(items, dtype=np.int32)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    pscore = np.ascontiguousarray(pscore, dtype=np.float64)
+    b = users.shape[0]
+    ex = np.empty(b, dtype=MF_EX_DTYPE)
+    level_ptr = np.empty(b + 1, dtype=np.int32)
+    cache_items = np.empty(max(cache_cap, 1), dtype=np.int32)
+    n_levels, n_cached = C.c_int32(0), C.c_int32(0)
+    _lib.check(lib.rfm_mf_schedule_ex(users.ctypes.data, items.ctypes.data, y.ctypes.data,
+                                      pscore.ctypes.data, b, n_users, n_items, cache_cap,
+                                      ex.ctypes.data, level_ptr.ctypes.data, C.byref(n_levels),
+                                      cache_items.ctypes.data, C.byref(n_cached)))
+    return ex, level_ptr[: n_levels.value + 1].copy(), cache_items[: n_cached.value].copy()

@@ -195,9 +195,9 @@ def test_fm_fit_ragged_logs(rfm, k, batch, dense_cols, hot):
 
 
 def test_non_canonical_csr_inputs(rfm):
-    """CSR as SciPy allows it: duplicate column entries inside a row (each stored
-    entry counts on its own, as in X.dot / X.power(2)), unsorted indices, explicitly
-    stored zeros, int64 index arrays."""
+    """CSR as SciPy allows it: duplicate column entries inside a row (SciPy sums them
+    before squaring -- X.power(2) de-duplicates -- and so must we), unsorted indices,
+    explicitly stored zeros, int64 index arrays.  The caller's matrix is not modified."""
     pkg = rfm[0]
     rng = np.random.default_rng(11)
     n_rows, n_cols, z = 700, 60, 9
@@ -211,6 +211,7 @@ def test_non_canonical_csr_inputs(rfm):
         return {"features": X, "labels": (rng.random(m) < 0.5).astype(np.int64),
                 "pscores": rng.uniform(0.1, 1.0, size=m) ** 0.5}
     train, val = log(700), log(200)
+    nnz_before = train["features"].nnz
     kw = dict(n_epochs=5, n_factors=6, lr=1e-3, batch_size=256, seed=5)
     for hot in (0, -1, 2):
         model = _fm(pkg, n_features=n_cols, **kw)
@@ -220,7 +221,15 @@ def test_non_canonical_csr_inputs(rfm):
         assert rel_err(model.V(), ref["V"]) < TIGHT and rel_err(model.w(), ref["w"]) < TIGHT
         assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
         assert rel_err(model.predict(val["features"]),
-                       cpu_ref.fm_predict(val["features"], ref["w0"], ref["w"], ref["V"])) < TIGHT
+                       cpu_ref.fm_predict(val["features"].copy(), ref["w0"], ref["w"], ref["V"])) < TIGHT
+    # the oracle, like the reference, de-duplicates the matrices it is handed in place;
+    # this package must leave the caller's matrices as given
+    t2, v2 = log(700), log(200)
+    model = _fm(pkg, n_features=n_cols, **kw)
+    model.fit(t2, v2)
+    model.predict(v2["features"])
+    for X in (t2["features"], v2["features"]):
+        assert X.nnz in (nnz_before, 200 * z) and not X.has_canonical_format
 
 
 def test_saturated_logits_and_empty_inputs(rfm):

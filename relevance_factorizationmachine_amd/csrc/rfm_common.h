@@ -91,6 +91,60 @@ struct DevBuf {
   }
 };
 
+// ---------------------------------------------------------------------------
+// dispatch on the factor count: a row is handled by `lpr` consecutive lanes, each
+// owning `vec` adjacent factors in `nc` chunks (kernels are templates on the three)
+// ---------------------------------------------------------------------------
+struct Shape {
+  int lpr, vec, nc;
+};
+
+inline Shape shape_for(int k) {
+  RFM_REQUIRE(k >= 1 && k <= RFM_MAX_FACTORS, "n_factors=%d unsupported (1..%d)", k,
+              RFM_MAX_FACTORS);
+  Shape s;
+  s.vec = (k % 2 == 0) ? 2 : 1;
+  const int units = (k + s.vec - 1) / s.vec;
+  int lpr = 4;
+  while (lpr < units && lpr < 64) lpr *= 2;
+  s.lpr = lpr;
+  int nc = 1;
+  while (lpr * nc < units) nc *= 2;
+  s.nc = nc;
+  return s;
+}
+
+#define RFM_FOR_SHAPE(S, CALL)                                                         \
+  do {                                                                                 \
+    const ::rfm::Shape _s = (S);                                                       \
+    if (_s.vec == 2) {                                                                 \
+      if (_s.nc == 1) {                                                                \
+        switch (_s.lpr) {                                                              \
+          case 4: CALL(4, 2, 1); break;                                                \
+          case 8: CALL(8, 2, 1); break;                                                \
+          case 16: CALL(16, 2, 1); break;                                              \
+          case 32: CALL(32, 2, 1); break;                                              \
+          default: CALL(64, 2, 1); break;                                              \
+        }                                                                              \
+      } else if (_s.nc == 2) { CALL(64, 2, 2); }                                       \
+      else if (_s.nc == 4) { CALL(64, 2, 4); }                                         \
+      else { CALL(64, 2, 8); }                                                         \
+    } else {                                                                           \
+      if (_s.nc == 1) {                                                                \
+        switch (_s.lpr) {                                                              \
+          case 4: CALL(4, 1, 1); break;                                                \
+          case 8: CALL(8, 1, 1); break;                                                \
+          case 16: CALL(16, 1, 1); break;                                              \
+          case 32: CALL(32, 1, 1); break;                                              \
+          default: CALL(64, 1, 1); break;                                              \
+        }                                                                              \
+      } else if (_s.nc == 2) { CALL(64, 1, 2); }                                       \
+      else if (_s.nc == 4) { CALL(64, 1, 4); }                                         \
+      else if (_s.nc == 8) { CALL(64, 1, 8); }                                         \
+      else { CALL(64, 1, 16); }                                                        \
+    }                                                                                  \
+  } while (0)
+
 }  // namespace rfm
 
 struct rfm_ctx {
@@ -98,7 +152,6 @@ struct rfm_ctx {
   hipStream_t stream = nullptr;
   int32_t n_cu = 256;
   rfm::DevBuf loss_partials;  // per-block partial sums of the loss reduction
-  rfm::DevBuf pred_scratch;   // scores when the caller does not want them
   void* comm = nullptr;       // RCCL communicator (rfm_comm_init), or null
   int32_t comm_ranks = 0;
   // per-kernel timing (rfm_profile_begin/end): 4 events per recorded step

@@ -58,61 +58,8 @@ namespace rfm {
 constexpr size_t kHotLdsBudget = 56 << 10;
 constexpr int kMaxHot = 160;  // beyond this the slab traffic outweighs what the class saves
 
-// ---------------------------------------------------------------------------
-// dispatch on the factor count
-// ---------------------------------------------------------------------------
-struct Shape {
-  int lpr, vec, nc;
-};
-
-inline Shape shape_for(int k) {
-  RFM_REQUIRE(k >= 1 && k <= RFM_MAX_FACTORS, "n_factors=%d unsupported (1..%d)", k,
-              RFM_MAX_FACTORS);
-  Shape s;
-  s.vec = (k % 2 == 0) ? 2 : 1;
-  const int units = (k + s.vec - 1) / s.vec;
-  int lpr = 4;
-  while (lpr < units && lpr < 64) lpr *= 2;
-  s.lpr = lpr;
-  int nc = 1;
-  while (lpr * nc < units) nc *= 2;
-  s.nc = nc;
-  return s;
-}
-
 // slots per window of fm_consume_kernel for a lane-group width (WinShape<LPR>::WIN)
 inline int window_slots(int lpr) { return lpr >= 64 ? 64 : (lpr == 32 ? 64 : 4 * lpr); }
-
-#define RFM_FOR_SHAPE(S, CALL)                                                         \
-  do {                                                                                 \
-    const ::rfm::Shape _s = (S);                                                       \
-    if (_s.vec == 2) {                                                                 \
-      if (_s.nc == 1) {                                                                \
-        switch (_s.lpr) {                                                              \
-          case 4: CALL(4, 2, 1); break;                                                \
-          case 8: CALL(8, 2, 1); break;                                                \
-          case 16: CALL(16, 2, 1); break;                                              \
-          case 32: CALL(32, 2, 1); break;                                              \
-          default: CALL(64, 2, 1); break;                                              \
-        }                                                                              \
-      } else if (_s.nc == 2) { CALL(64, 2, 2); }                                       \
-      else if (_s.nc == 4) { CALL(64, 2, 4); }                                         \
-      else { CALL(64, 2, 8); }                                                         \
-    } else {                                                                           \
-      if (_s.nc == 1) {                                                                \
-        switch (_s.lpr) {                                                              \
-          case 4: CALL(4, 1, 1); break;                                                \
-          case 8: CALL(8, 1, 1); break;                                                \
-          case 16: CALL(16, 1, 1); break;                                              \
-          case 32: CALL(32, 1, 1); break;                                              \
-          default: CALL(64, 1, 1); break;                                              \
-        }                                                                              \
-      } else if (_s.nc == 2) { CALL(64, 1, 2); }                                       \
-      else if (_s.nc == 4) { CALL(64, 1, 4); }                                         \
-      else if (_s.nc == 8) { CALL(64, 1, 8); }                                         \
-      else { CALL(64, 1, 16); }                                                        \
-    }                                                                                  \
-  } while (0)
 
 // forward launch geometry: 512-thread workgroups whose lane groups keep several
 // rows in flight once the batch fills the chip with them (two per CU: few

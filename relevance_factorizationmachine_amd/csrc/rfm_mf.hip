@@ -481,59 +481,9 @@ __global__ __launch_bounds__(kSeqBlock) void mf_sgd_seq_ex_kernel(MfExArgs a) {
   }
 }
 
-struct MfShape {
-  int lpr, vec, nc;
-};
-
-inline MfShape mf_shape_for(int k) {
-  RFM_REQUIRE(k >= 1 && k <= RFM_MAX_FACTORS, "n_factors=%d unsupported (1..%d)", k,
-              RFM_MAX_FACTORS);
-  MfShape s;
-  s.vec = (k % 2 == 0) ? 2 : 1;
-  const int units = (k + s.vec - 1) / s.vec;
-  int lpr = 4;
-  while (lpr < units && lpr < 64) lpr *= 2;
-  s.lpr = lpr;
-  int nc = 1;
-  while (lpr * nc < units) nc *= 2;
-  s.nc = nc;
-  return s;
-}
-
-#define RFM_MF_FOR_SHAPE(S, CALL)                                                      \
-  do {                                                                                 \
-    const ::rfm::MfShape _s = (S);                                                     \
-    if (_s.vec == 2) {                                                                 \
-      if (_s.nc == 1) {                                                                \
-        switch (_s.lpr) {                                                              \
-          case 4: CALL(4, 2, 1); break;                                                \
-          case 8: CALL(8, 2, 1); break;                                                \
-          case 16: CALL(16, 2, 1); break;                                              \
-          case 32: CALL(32, 2, 1); break;                                              \
-          default: CALL(64, 2, 1); break;                                              \
-        }                                                                              \
-      } else if (_s.nc == 2) { CALL(64, 2, 2); }                                       \
-      else if (_s.nc == 4) { CALL(64, 2, 4); }                                         \
-      else { CALL(64, 2, 8); }                                                         \
-    } else {                                                                           \
-      if (_s.nc == 1) {                                                                \
-        switch (_s.lpr) {                                                              \
-          case 4: CALL(4, 1, 1); break;                                                \
-          case 8: CALL(8, 1, 1); break;                                                \
-          case 16: CALL(16, 1, 1); break;                                              \
-          case 32: CALL(32, 1, 1); break;                                              \
-          default: CALL(64, 1, 1); break;                                              \
-        }                                                                              \
-      } else if (_s.nc == 2) { CALL(64, 1, 2); }                                       \
-      else if (_s.nc == 4) { CALL(64, 1, 4); }                                         \
-      else if (_s.nc == 8) { CALL(64, 1, 8); }                                         \
-      else { CALL(64, 1, 16); }                                                        \
-    }                                                                                  \
-  } while (0)
-
 static void mf_predict_launch(rfm_ctx* ctx, MfPredArgs a, double* d_out_loss) {
   if (a.n_rows <= 0) return;
-  const MfShape s = mf_shape_for(a.k);
+  const Shape s = shape_for(a.k);
   const int gpb = kMfBlock / s.lpr;
   const int grid = int(std::max<int64_t>(
       1, std::min<int64_t>((a.n_rows + gpb - 1) / gpb, int64_t(ctx->n_cu) * 8)));
@@ -543,7 +493,7 @@ static void mf_predict_launch(rfm_ctx* ctx, MfPredArgs a, double* d_out_loss) {
   }
 #define RFM_CALL_MFP(L, Vv, N) \
   hipLaunchKernelGGL((mf_predict_kernel<L, Vv, N>), dim3(grid), dim3(kMfBlock), 0, ctx->stream, a)
-  RFM_MF_FOR_SHAPE(s, RFM_CALL_MFP);
+  RFM_FOR_SHAPE(s, RFM_CALL_MFP);
 #undef RFM_CALL_MFP
   if (d_out_loss)
     hipLaunchKernelGGL(mf_loss_finish_kernel, dim3(1), dim3(kMfBlock), 0, ctx->stream,
@@ -624,7 +574,7 @@ int32_t rfm_mf_sgd_levels(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d
                     h_level_ptr && d_level_ptr && d_P && d_Q && d_bu && d_bi,
                 "null pointer");
     RFM_REQUIRE(n_levels >= 0, "negative n_levels");
-    const MfShape s = mf_shape_for(n_factors);
+    const Shape s = shape_for(n_factors);
     MfSgdArgs a{};
     a.users = d_users;
     a.items = d_items;
@@ -655,7 +605,7 @@ int32_t rfm_mf_sgd_levels(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d
 #define RFM_CALL_WIDE(L, Vv, N)                                                               \
   hipLaunchKernelGGL((mf_sgd_wide_kernel<L, Vv, N>), dim3(grid), dim3(kMfBlock), 0, ctx->stream, \
                      a)
-        RFM_MF_FOR_SHAPE(s, RFM_CALL_WIDE);
+        RFM_FOR_SHAPE(s, RFM_CALL_WIDE);
 #undef RFM_CALL_WIDE
         ++lev;
       } else {
@@ -665,7 +615,7 @@ int32_t rfm_mf_sgd_levels(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d
         a.hi = end;
 #define RFM_CALL_SEQ(L, Vv, N) \
   hipLaunchKernelGGL((mf_sgd_seq_kernel<L, Vv, N>), dim3(1), dim3(kSeqBlock), 0, ctx->stream, a)
-        RFM_MF_FOR_SHAPE(s, RFM_CALL_SEQ);
+        RFM_FOR_SHAPE(s, RFM_CALL_SEQ);
 #undef RFM_CALL_SEQ
         lev = end;
       }
@@ -684,7 +634,7 @@ int32_t rfm_mf_sgd_levels_ex(rfm_ctx* ctx, const void* d_ex, const int32_t* h_le
                 "null pointer");
     RFM_REQUIRE(n_levels >= 0 && n_cached >= 0 && (n_cached == 0 || d_cache_items),
                 "bad schedule");
-    const MfShape s = mf_shape_for(n_factors);
+    const Shape s = shape_for(n_factors);
     const size_t lds = size_t(n_cached) * size_t(n_factors + 2) * sizeof(double);
     RFM_REQUIRE(lds <= (64u << 10), "item cache of %d rows does not fit LDS", n_cached);
     MfExArgs a{};
@@ -714,7 +664,7 @@ int32_t rfm_mf_sgd_levels_ex(rfm_ctx* ctx, const void* d_ex, const int32_t* h_le
 #define RFM_CALL_WIDE_EX(L, Vv, N)                                                            \
   hipLaunchKernelGGL((mf_sgd_wide_ex_kernel<L, Vv, N>), dim3(grid), dim3(kMfBlock), 0,        \
                      ctx->stream, a)
-        RFM_MF_FOR_SHAPE(s, RFM_CALL_WIDE_EX);
+        RFM_FOR_SHAPE(s, RFM_CALL_WIDE_EX);
 #undef RFM_CALL_WIDE_EX
         ++lev;
       } else {
@@ -725,7 +675,7 @@ int32_t rfm_mf_sgd_levels_ex(rfm_ctx* ctx, const void* d_ex, const int32_t* h_le
 #define RFM_CALL_SEQ_EX(L, Vv, N)                                                              \
   hipLaunchKernelGGL((mf_sgd_seq_ex_kernel<L, Vv, N>), dim3(1), dim3(kSeqBlock), lds, ctx->stream, \
                      a)
-        RFM_MF_FOR_SHAPE(s, RFM_CALL_SEQ_EX);
+        RFM_FOR_SHAPE(s, RFM_CALL_SEQ_EX);
 #undef RFM_CALL_SEQ_EX
         lev = end;
       }
@@ -745,7 +695,7 @@ int32_t rfm_mf_sgd_hogwild(rfm_ctx* ctx, const int32_t* d_users, const int32_t* 
                 "null pointer");
     RFM_REQUIRE(batch >= 0 && batch < (int64_t(1) << 31), "batch out of range");
     if (batch == 0) return;
-    const MfShape s = mf_shape_for(n_factors);
+    const Shape s = shape_for(n_factors);
     MfSgdArgs a{};
     a.users = d_users;
     a.items = d_items;
@@ -768,7 +718,7 @@ int32_t rfm_mf_sgd_hogwild(rfm_ctx* ctx, const int32_t* d_users, const int32_t* 
 #define RFM_CALL_HOG(L, Vv, N)                                                                \
   hipLaunchKernelGGL((mf_sgd_wide_kernel<L, Vv, N>), dim3(grid), dim3(kMfBlock), 0, ctx->stream, \
                      a)
-    RFM_MF_FOR_SHAPE(s, RFM_CALL_HOG);
+    RFM_FOR_SHAPE(s, RFM_CALL_HOG);
 #undef RFM_CALL_HOG
     RFM_HIP_CHECK(hipGetLastError());
   });

@@ -270,6 +270,32 @@ int32_t rfm_mf_sgd_hogwild(rfm_ctx* ctx, const int32_t* d_users, const int32_t* 
                            double* d_bu, double* d_bi, double b, int32_t n_factors, double lr,
                            double reg);
 
+/* ---- per-iteration validation metric ---------------------
+ * IPS-DCG@k of ValEvaluator.evaluate (utils/evaluate.py:183-207 with
+ * utils/metrics.py:53-80), the value src/fm.py:104-110 and src/mf.py:126-132
+ * append to val_metrics every iteration.  The frame's rows are grouped by user
+ * (groups in ascending user order, rows of a group in frame order -- what
+ * DataFrame.groupby("user").agg(list) yields): group g holds positions
+ * d_seg_ptr[g] .. d_seg_ptr[g+1]; d_labels / d_pscores are indexed by position,
+ * the score of position j is d_scores[d_rows[j]] (d_rows == NULL: d_scores[j]).
+ * Per group: rows ranked by descending score, groups whose labels sum to zero are
+ * left out, value = y0/p0 + sum_{r=1..k-1} y_r / (p_r * log2(r+1)); d_out[0] = mean
+ * over the groups that count (nan if none).  Equal scores rank the later position
+ * first, i.e. argsort(kind="stable")[::-1]; NumPy's default sort, which the
+ * reference calls, is not stable and orders ties differently from CPU to CPU, so
+ * d_out[1] = number of counted groups whose value depends on that order (a tie
+ * reaching into the first k ranks between rows of different label or propensity,
+ * or a NaN score, which is never ranked here).  With d_out[1] == 0 the value is the
+ * reference's; otherwise the caller decides (the Python mirror re-evaluates such an
+ * iteration with the evaluator's own host code).  d_pscores == NULL means all ones
+ * (the Naive estimator's ones_pscore column; also calc_dcg_at_k of
+ * utils/metrics.py:83-107).  d_user_scratch: 3*n_segments doubles; after the call
+ * [0, n) holds the per-group values, [n, 2n) 1.0 / 0.0 for counted / left out and
+ * [2n, 3n) 1.0 for the order-dependent groups. */
+int32_t rfm_val_dcg(rfm_ctx* ctx, const double* d_scores, const int32_t* d_seg_ptr,
+                    const int32_t* d_rows, const double* d_labels, const double* d_pscores,
+                    int32_t n_segments, int32_t k, double* d_user_scratch, double* d_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,7 @@ from relevance_factorizationmachine_amd.runtime import DeviceCSR, Runtime, sampl
 B = int(os.environ.get("ABL_BATCH", "65536")); K = 20; k = int(os.environ.get("ABL_K", "32"))
 shape = synth.SHAPES[os.environ.get("ABL_SHAPE", "kuairec_big")]
 cache = "/tmp/abl_%%s.npz" %% shape.name
-train, _ = synth.make_log(shape, "FM", "IPS", seed=0, n_val=16)
+train, _ = synth.make_log(shape, "FM", "IPS", seed=0, n_val=16, n_train=int(os.environ.get("ABL_NTRAIN", "0")) or None)
 X = train["features"]; n = X.shape[1]
 rt = Runtime.get(0)
 m = FactorizationMachines(estimator="IPS", n_epochs=1, n_factors=k, lr=9e-6, batch_size=B, seed=12345, n_features=n)

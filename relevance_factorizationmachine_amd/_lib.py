@@ -17,7 +17,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 # RFM_LIB_PATH: load another build of the same ABI (timing experiments under profiles/)
 LIB_PATH = os.environ.get("RFM_LIB_PATH") or os.path.join(PKG_DIR, "librfm_hip.so")
-SOURCES = ["rfm_capi.hip", "rfm_fm.hip", "rfm_mf.hip", "rfm_host.cpp", "rfm_comm.cpp"]
+SOURCES = ["rfm_capi.hip", "rfm_fm.hip", "rfm_mf.hip", "rfm_eval.hip", "rfm_host.cpp", "rfm_comm.cpp"]
 HEADERS = [os.path.join(CSRC, "rfm_common.h"), os.path.join(CSRC, "rfm_fm_kernels.hpp"),
            os.path.join(os.path.dirname(PKG_DIR), "include", "rfm_hip.h")]
 
@@ -107,6 +107,7 @@ SIGNATURES = {
                              _f64],
     "rfm_mf_sgd_hogwild": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _i32, _f64,
                            _f64],
+    "rfm_val_dcg": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
 }
 
 _lib = None

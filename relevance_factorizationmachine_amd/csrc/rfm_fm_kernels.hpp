@@ -738,7 +738,9 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
     double ee[PLANES];
 #pragma unroll
     for (int pl = 0; pl < PLANES; ++pl) {
-      sr[pl] = a.slots[w0 + pl * LPR + l];
+      // unmarked lanes read the window's first record: only the lines of marked
+      // slots are fetched (a batch marks a few percent of the log's slots)
+      sr[pl] = a.slots[tk[pl] >= 0 ? w0 + pl * LPR + l : w0];
       ee[pl] = a.err[max(tk[pl], 0)];
     }
 #pragma unroll

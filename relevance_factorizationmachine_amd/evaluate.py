@@ -1,0 +1,183 @@
+"""The per-iteration validation metric of ``fit(..., evaluator=)`` on the device
+(SURVEY.md 8f N1).
+
+The reference calls ``evaluator.evaluate(y_scores=predict(...), estimator=...)``
+after every iteration (``src/fm.py:104-110``, ``src/mf.py:126-132``); for its
+``ValEvaluator`` that is a pandas ``groupby("user")`` plus one ``argsort`` per
+user on the host (``utils/evaluate.py:183-239``).  When the object handed in is
+recognisably such an evaluator -- a frame ``interaction_df`` with the columns
+``user, label, pscore, ones_pscore``, a ranking depth ``k`` and
+``metric_name == "DCG"`` -- the same IPS-DCG@k is computed by ``rfm_val_dcg``
+from the scores that are already in HBM, and only the list of metric values
+comes back when ``fit`` ends.  Any other object keeps the host callback.
+
+Ranking ties: the device ranks equal scores later-row-first
+(``argsort(kind="stable")[::-1]``).  NumPy's default sort, which the reference
+calls, is not stable and its tie order changes from CPU to CPU, and saturated
+sigmoid scores (exactly 0.0 / 1.0) make ties common.  ``rfm_val_dcg`` therefore
+counts the users whose value depends on the tie order; an iteration with any such
+user is re-evaluated by the evaluator's own ``evaluate`` on the host
+(``EvalLoop``), so ``val_metrics`` is what the host callback would have produced.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from .runtime import Runtime
+
+_COLUMNS = ("user", "label", "pscore", "ones_pscore")
+
+
+def group_by_user(users: np.ndarray):
+    """``(order, seg_ptr)``: frame rows grouped by ascending user, rows of a
+    group in frame order (``groupby("user").agg(list)``, evaluate.py:225-239)."""
+    users = np.asarray(users)
+    n = users.shape[0]
+    order = np.argsort(users, kind="stable").astype(np.int32)
+    su = users[order]
+    cuts = np.flatnonzero(su[1:] != su[:-1]) + 1
+    seg_ptr = (np.concatenate(([0], cuts, [n])) if n else np.zeros(1)).astype(np.int32)
+    return order, seg_ptr
+
+
+class DeviceValFrame:
+    """A validation frame resident in HBM in grouped order."""
+
+    def __init__(self, rt: Runtime, users, labels, pscores: Optional[np.ndarray], k: int):
+        users = np.asarray(users)
+        if users.ndim != 1:
+            raise ValueError("users must be a 1-D array")
+        n = users.shape[0]
+        if k < 1:
+            raise ValueError("k (ranking positions) must be >= 1")
+        self.rt, self.k, self.n_rows = rt, int(k), int(n)
+        order, seg_ptr = group_by_user(users)
+        self.n_segments = int(seg_ptr.shape[0] - 1)
+        labels = np.asarray(labels, dtype=np.float64)
+        if labels.shape != (n,):
+            raise ValueError("labels must match the frame's rows")
+        self.rows = rt.upload(order if n else np.zeros(1, np.int32))
+        self.seg_ptr = rt.upload(seg_ptr)
+        self.labels = rt.upload(labels[order] if n else np.zeros(1))
+        self.pscores = None
+        if pscores is not None:
+            pscores = np.asarray(pscores, dtype=np.float64)
+            if pscores.shape != (n,):
+                raise ValueError("pscores must match the frame's rows")
+            self.pscores = rt.upload(pscores[order] if n else np.zeros(1))
+        self.scratch = rt.empty((max(3 * self.n_segments, 1),), self.labels.dtype)
+
+    def dcg_into(self, d_scores, out_ptr: int) -> None:
+        """Enqueue the metric of ``d_scores`` (device, frame order): the value and the
+        number of users it is tie-order dependent for land at ``out_ptr`` (2 doubles)."""
+        rt = self.rt
+        _lib.check(rt.lib.rfm_val_dcg(
+            rt.ctx, d_scores.data_ptr(), self.seg_ptr.data_ptr(), self.rows.data_ptr(),
+            self.labels.data_ptr(), None if self.pscores is None else self.pscores.data_ptr(),
+            self.n_segments, self.k, self.scratch.data_ptr(), out_ptr))
+
+    def dcg_checked(self, scores):
+        """``(value, n_order_dependent_users)`` of host or device scores (frame order)."""
+        rt = self.rt
+        d = scores if hasattr(scores, "data_ptr") else rt.upload(np.asarray(scores, dtype=np.float64))
+        if d.shape[0] != self.n_rows:
+            raise ValueError(f"{d.shape[0]} scores for a frame of {self.n_rows} rows")
+        out = rt.empty((2,), self.labels.dtype)
+        self.dcg_into(d, out.data_ptr())
+        rt.sync()
+        o = out.cpu().numpy()
+        return float(o[0]), int(o[1])
+
+    def dcg(self, scores) -> float:
+        """The metric under the device's tie rule, synchronously."""
+        return self.dcg_checked(scores)[0]
+
+    def per_user(self):
+        """``(values, counted, order_dependent)`` of the last call, one entry per user group."""
+        self.rt.sync()
+        s = self.scratch.cpu().numpy()
+        n = self.n_segments
+        return s[:n].copy(), s[n: 2 * n] != 0.0, s[2 * n: 3 * n] != 0.0
+
+
+class EvalLoop:
+    """The evaluator hook of a ``fit()`` loop, computed on the device.
+
+    Per iteration the caller writes the evaluator's scores into ``slot(epoch)`` and
+    calls ``done(epoch)``; nothing returns to the host until a chunk of iterations is
+    complete.  Iterations whose value depends on the order of tied scores are then
+    handed, scores and all, to ``evaluator.evaluate`` -- the list ``finish()``
+    returns is what calling the evaluator every iteration would have produced."""
+
+    CHUNK_BYTES = 1 << 30
+
+    def __init__(self, rt: Runtime, frame: DeviceValFrame, evaluator, estimator: str, n_epochs: int):
+        self.rt, self.frame, self.evaluator, self.estimator = rt, frame, evaluator, estimator
+        self.n_epochs = n_epochs
+        self.chunk = int(max(1, min(max(n_epochs, 1), self.CHUNK_BYTES // max(8 * frame.n_rows, 8))))
+        self.scores = rt.empty((self.chunk, max(frame.n_rows, 1)), frame.labels.dtype)
+        self.out = rt.empty((max(n_epochs, 1), 2), frame.labels.dtype)
+        self.values: list = []
+        self.host_calls = 0
+        self._flushed = 0
+
+    def slot(self, epoch: int):
+        """Device tensor the scores of iteration ``epoch`` go to."""
+        return self.scores[epoch % self.chunk]
+
+    def done(self, epoch: int) -> None:
+        self.frame.dcg_into(self.slot(epoch), self.out.data_ptr() + epoch * 16)
+        if (epoch + 1) % self.chunk == 0:
+            self._flush(epoch + 1)
+
+    def _flush(self, upto: int) -> None:
+        if upto <= self._flushed:
+            return
+        self.rt.sync()
+        o = self.out[self._flushed:upto].cpu().numpy()
+        for i, epoch in enumerate(range(self._flushed, upto)):
+            if o[i, 1] != 0.0:
+                y_scores = self.slot(epoch)[: self.frame.n_rows].cpu().numpy()
+                self.values.append(self.evaluator.evaluate(y_scores=y_scores, estimator=self.estimator))
+                self.host_calls += 1
+            else:
+                self.values.append(float(o[i, 0]))
+        self._flushed = upto
+
+    def finish(self, n_done: int) -> list:
+        self._flush(n_done)
+        return self.values
+
+
+def recognise(evaluator, estimator: str):
+    """``(users, labels, pscores, k)`` of a ValEvaluator-like object, or ``None``
+    when it is something else (then the caller keeps the host callback)."""
+    frame = getattr(evaluator, "interaction_df", None)
+    k = getattr(evaluator, "k", None)
+    if frame is None or not isinstance(k, (int, np.integer)) or k < 1:
+        return None
+    if getattr(evaluator, "metric_name", None) != "DCG":
+        return None
+    try:
+        cols = {c: np.asarray(frame[c]) for c in _COLUMNS}
+    except (KeyError, TypeError, IndexError, ValueError):
+        return None
+    n = cols["user"].shape[0]
+    if any(v.ndim != 1 or v.shape[0] != n for v in cols.values()):
+        return None
+    # evaluate.py:222: pscore for IPS, ones_pscore for every other estimator
+    p = cols["pscore"] if estimator == "IPS" else cols["ones_pscore"]
+    return cols["user"], cols["label"], p, int(k)
+
+
+def device_frame(rt: Runtime, evaluator, estimator: str, n_scores: int) -> Optional[DeviceValFrame]:
+    """The device form of ``evaluator`` if it is recognised and matches the
+    ``n_scores`` rows its features produce; else ``None``."""
+    got = recognise(evaluator, estimator)
+    if got is None or got[0].shape[0] != n_scores:
+        return None
+    users, labels, pscores, k = got
+    return DeviceValFrame(rt, users, labels, pscores, k)

@@ -18,6 +18,7 @@ import numpy as np
 
 from . import _lib
 from .base import LOSS_EPS, PointwiseBaseRecommender
+from .evaluate import EvalLoop, device_frame
 from .optimizer import DeviceSGD
 from .runtime import CsrCache, DeviceCSR, Runtime, sample_batches
 
@@ -76,6 +77,9 @@ class FactorizationMachines(PointwiseBaseRecommender):
     # entries per batch are summed on chip (0 = library default, -1 = never,
     # which makes every sum's order fixed and a fit bitwise reproducible).
     hot_min_count = 0
+    # Not a constructor argument: a ValEvaluator-like ``evaluator`` (see evaluate.py) is
+    # computed on the device; False keeps the host callback for every evaluator.
+    device_evaluator = True
 
     def __post_init__(self) -> None:
         # src/fm.py:31-53 -- the reference's NumPy calls, in its draw order
@@ -136,12 +140,34 @@ class FactorizationMachines(PointwiseBaseRecommender):
             if self.evaluator is None:
                 run(0, self.n_epochs)
             else:
-                # the evaluator is a host callback: one iteration per enqueue
-                for epoch in range(self.n_epochs):
-                    run(epoch, 1)
-                    y_scores = self.predict(X=self.evaluator.features[self.model_name])
-                    self.val_metrics.append(
-                        self.evaluator.evaluate(y_scores=y_scores, estimator=self.estimator))
+                ev_X = self.evaluator.features[self.model_name]
+                frame = (device_frame(rt, self.evaluator, self.estimator, ev_X.shape[0])
+                         if self.device_evaluator else None)
+                if frame is None:
+                    # an evaluator of unknown kind is a host callback: one iteration per enqueue
+                    for epoch in range(self.n_epochs):
+                        run(epoch, 1)
+                        y_scores = self.predict(X=ev_X)
+                        self.val_metrics.append(
+                            self.evaluator.evaluate(y_scores=y_scores, estimator=self.estimator))
+                else:
+                    # ValEvaluator's IPS-DCG@k from the scores in HBM (rfm_val_dcg); only
+                    # iterations whose value hangs on the order of tied scores go to the host
+                    if ev_X.shape[1] != self.n_features:
+                        raise ValueError(
+                            f"X has {ev_X.shape[1]} columns, model has {self.n_features}")
+                    ev = self._csr_cache.get(ev_X)
+                    loop = EvalLoop(rt, frame, self.evaluator, self.estimator, self.n_epochs)
+                    for epoch in range(self.n_epochs):
+                        run(epoch, 1)
+                        _lib.check(rt.lib.rfm_fm_forward(
+                            rt.ctx, ev.indptr.data_ptr(), ev.indices.data_ptr(), ev.values.data_ptr(),
+                            None, ev.shape[0], self.w0.dev.data_ptr(), self.w.dev.data_ptr(),
+                            self.V.dev.data_ptr(), self.n_features, self.n_factors,
+                            loop.slot(epoch).data_ptr()))
+                        loop.done(epoch)
+                    self.val_metrics.extend(loop.finish(self.n_epochs))
+                    self.evaluator_host_calls = loop.host_calls
             rt.sync()
         finally:
             rt.sync()

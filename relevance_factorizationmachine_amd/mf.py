@@ -16,6 +16,7 @@ import numpy as np
 
 from . import _lib
 from .base import LOSS_EPS, PointwiseBaseRecommender
+from .evaluate import EvalLoop, device_frame
 from .optimizer import DeviceSGD
 from .runtime import Runtime, mf_schedule_ex, sample_batches
 
@@ -53,6 +54,9 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
     # schedule.  True: HOGWILD-style unordered updates (rfm_mf_sgd_hogwild) -- a
     # throughput mode whose parameters do NOT match the reference to 1e-5.
     hogwild = False
+    # Not a constructor argument: a ValEvaluator-like ``evaluator`` (see evaluate.py) is
+    # computed on the device; False keeps the host callback for every evaluator.
+    device_evaluator = True
 
     def __post_init__(self) -> None:
         # src/mf.py:34-66 -- the reference's NumPy calls, in its draw order
@@ -112,6 +116,17 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
         # item rows the sequential kernel may keep in LDS (48 KiB of rows + bias)
         cache_cap = int(min(1024, (48 << 10) // ((self.n_factors + 2) * 8)))
 
+        ev_frame = ev_pairs = ev_loop = None
+        if self.evaluator is not None:
+            ev_X = self.evaluator.features[self.model_name]
+            if self.device_evaluator:
+                ev_frame = device_frame(rt, self.evaluator, self.estimator, int(np.asarray(ev_X).shape[0]))
+            if ev_frame is not None:
+                # ValEvaluator's IPS-DCG@k from scores that stay in HBM (rfm_val_dcg)
+                ev_pairs = DevicePairs(rt, ev_X)
+                self._check_ids(ev_pairs)
+                ev_loop = EvalLoop(rt, ev_frame, self.evaluator, self.estimator, self.n_epochs)
+
         for epoch in range(self.n_epochs):
             rows = ids[epoch]
             ids_ptr = d_ids.data_ptr() + epoch * self.batch_size * 4
@@ -140,7 +155,12 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
             _lib.check(rt.lib.rfm_mf_predict_loss(
                 rt.ctx, va.users.data_ptr(), va.items.data_ptr(), vy.data_ptr(), vp.data_ptr(),
                 None, va.n, *params, b, self.n_factors, LOSS_EPS, None, vl.data_ptr() + epoch * 8))
-            if self.evaluator is not None:
+            if ev_frame is not None:
+                _lib.check(rt.lib.rfm_mf_predict(
+                    rt.ctx, ev_pairs.users.data_ptr(), ev_pairs.items.data_ptr(), None, ev_pairs.n,
+                    *params, b, self.n_factors, ev_loop.slot(epoch).data_ptr()))
+                ev_loop.done(epoch)
+            elif self.evaluator is not None:
                 y_scores = self.predict(self.evaluator.features[self.model_name])
                 self.val_metrics.append(
                     self.evaluator.evaluate(y_scores=y_scores, estimator=self.estimator))
@@ -148,6 +168,9 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
                 rt.sync()
                 keep.clear()
         rt.sync()
+        if ev_frame is not None:
+            self.val_metrics.extend(ev_loop.finish(self.n_epochs))
+            self.evaluator_host_calls = ev_loop.host_calls
         return tl.cpu().numpy().tolist(), vl.cpu().numpy().tolist()
 
     # -------------------------------------------------------------- predict

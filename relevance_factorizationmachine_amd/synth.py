@@ -199,3 +199,10 @@ def interaction_frame(val: dict, pairs: np.ndarray) -> dict:
         "pscore": val["pscores"].astype(np.float64),
         "ones_pscore": np.ones(len(val["labels"]), dtype=np.float64),
     }
+
+
+def first_occurrences(pairs: np.ndarray) -> np.ndarray:
+    """Ascending row numbers of the first occurrence of every (user, item) pair."""
+    pairs = np.asarray(pairs)
+    key = pairs[:, 0].astype(np.int64) * (int(pairs[:, 1].max()) + 1) + pairs[:, 1]
+    return np.sort(np.unique(key, return_index=True)[1])

@@ -134,3 +134,40 @@ def test_mf_schedule_ex_records(seed, cap):
     ex2, _, cache2 = mf_schedule_ex(users, items, y, p, nu, ni, cap)
     np.testing.assert_array_equal(ex, ex2)
     np.testing.assert_array_equal(cache, cache2)
+
+
+def test_evaluator_grouping_and_recognition():
+    """Host half of the device evaluator (no GPU): the grouping equals pandas'
+    groupby("user").agg(list) order, and only ValEvaluator-like objects are recognised."""
+    import pandas as pd
+
+    from oracle import cpu_ref
+    from relevance_factorizationmachine_amd import evaluate
+
+    rng = np.random.default_rng(0)
+    users = rng.integers(0, 50, size=1000) * 7
+    order, seg_ptr = evaluate.group_by_user(users)
+    assert order.dtype == np.int32 and seg_ptr.dtype == np.int32
+    slices = cpu_ref._per_user_slices(users)
+    assert len(slices) == len(seg_ptr) - 1
+    for g, rows in enumerate(slices):
+        np.testing.assert_array_equal(order[seg_ptr[g]:seg_ptr[g + 1]], rows)
+    df = pd.DataFrame({"user": users, "row": np.arange(1000)})
+    grouped = df.groupby("user").agg(list)
+    for g, rows in enumerate(grouped["row"]):
+        np.testing.assert_array_equal(order[seg_ptr[g]:seg_ptr[g + 1]], rows)
+    o0, s0 = evaluate.group_by_user(np.zeros(0, np.int64))
+    assert o0.shape == (0,) and s0.tolist() == [0]
+
+    frame = pd.DataFrame({"user": users, "item": users, "label": (users % 2), "pscore": np.full(1000, 0.5),
+                          "ones_pscore": np.ones(1000)})
+
+    class Val:
+        k, metric_name, interaction_df = 5, "DCG", frame
+
+    u, y, p, k = evaluate.recognise(Val(), "IPS")
+    assert k == 5 and p[0] == 0.5 and u.shape == (1000,) and y.sum() == (users % 2).sum()
+    assert evaluate.recognise(Val(), "Naive")[2][0] == 1.0
+    Val.metric_name = "Recall"
+    assert evaluate.recognise(Val(), "IPS") is None
+    assert evaluate.recognise(object(), "IPS") is None

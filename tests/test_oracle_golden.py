@@ -135,6 +135,20 @@ def test_dcg_checkers():
         assert got == pytest.approx(float(g[f"g2_val_dcg_{est}"]), rel=1e-13)
 
 
+def test_dcg_checkers_distinct_scores():
+    """The evaluator fixture without order-dependent ties (make_golden_eval.py)."""
+    g = load_golden("val_dcg_distinct")
+    frame = {k: g[k] for k in ("user", "item", "label", "pscore", "ones_pscore")}
+    for est in ("IPS", "Naive"):
+        for k in (1, 3, 5, 10):
+            assert cpu_ref.val_dcg(frame, g["scores"], est, k=k) == pytest.approx(
+                float(g[f"val_dcg_{est}_k{k}"]), rel=1e-13)
+        tied = dict(frame, label=g["tied_label"], pscore=g["tied_pscore"])
+        assert cpu_ref.val_dcg(tied, g["tied_scores"], est) == pytest.approx(
+            float(g[f"tied_val_dcg_{est}"]), rel=1e-13)
+    np.testing.assert_allclose(cpu_ref.test_dcg(frame, g["scores"]), g["test_dcg"], rtol=1e-13)
+
+
 def test_logloss_and_sigmoid_edges():
     g = load_golden("logloss_cases")
     assert cpu_ref.ips_logloss(g["y"], g["scores"], g["pscores"]) == pytest.approx(float(g["loss"]), rel=1e-14)

@@ -384,6 +384,47 @@ def test_full_size_forward_permutation_invariance(rfm, big_log):
     assert rel_err(base, cpu_ref.fm_predict(X, w0, w, V)) < TIGHT
 
 
+# --------------------------------------------------------------------------
+# configs 4 and 5 of BASELINE.json at their parameter sizes (V 563 MB, P 1 GB)
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("batch", [2000, 65536])
+def test_config4_fit_vs_oracle(rfm, batch):
+    """1M users x 100k items, n = 1 100 110 columns, k = 64: two fit() iterations against
+    the oracle's closed-form step (the log is cut to 300k rows so the CPU side takes seconds;
+    the parameter tables keep their full size, so V streams from HBM here)."""
+    pkg = rfm[0]
+    sh = synth.SHAPES["synthetic_1m"]
+    train, val = synth.make_log(sh, "FM", "IPS", seed=0, n_train=300_000, n_val=5_000)
+    n = train["features"].shape[1]
+    assert n == 1_100_110
+    kw = dict(n_epochs=2, n_factors=64, lr=9e-6, batch_size=batch, seed=12345)
+    model = pkg.FactorizationMachines(estimator="IPS", n_features=n, **kw)
+    tr, va = model.fit(train, val)
+    ref = cpu_ref.fm_fit(train, val, form="closed", **kw)
+    assert rel_err(model.V(), ref["V"]) < TIGHT
+    assert rel_err(model.w(), ref["w"]) < TIGHT
+    assert rel_err(model.w0(), ref["w0"]) < TIGHT
+    assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
+    assert rel_err(model.predict(val["features"]), cpu_ref.fm_predict(val["features"], ref["w0"], ref["w"], ref["V"])) < TIGHT
+
+
+def test_config5_mf_fit_vs_oracle(rfm):
+    """MF with P 1M x 128 and Q 100k x 128: two sequential-SGD batches against the oracle."""
+    pkg = rfm[0]
+    sh = synth.SHAPES["synthetic_1m"]
+    train, val = synth.make_log(sh, "MF", "IPS", seed=0, n_train=300_000, n_val=5_000)
+    kw = dict(n_epochs=2, n_factors=128, lr=0.01, batch_size=2000, seed=12345, n_users=sh.n_users,
+              n_items=sh.n_items, reg=0.5)
+    model = pkg.LogisticMatrixFactorization(estimator="IPS", **kw)
+    tr, va = model.fit(train, val)
+    ref = cpu_ref.mf_fit(train, val, **kw)
+    for nm in ("P", "Q", "b_u", "b_i"):
+        assert rel_err(getattr(model, nm)(), ref[nm]) < TIGHT, nm
+    assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
+    assert rel_err(model.predict(val["features"]),
+                   cpu_ref.mf_predict(val["features"], ref["P"], ref["Q"], ref["b_u"], ref["b_i"], ref["b"])) < TIGHT
+
+
 def test_import_shims_resolve_to_this_package(rfm):
     pkg = rfm[0]
     from src.fm import FactorizationMachines as FM

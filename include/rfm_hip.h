@@ -47,6 +47,10 @@ enum {
 
 /* limits of this build */
 #define RFM_MAX_FACTORS 1024
+/* levels the sequential MF kernel reads an example's rows ahead of its own level */
+#define RFM_MF_READ_AHEAD 4
+/* rfm_mf_schedule_ex: gap of an example whose user row no earlier example of the batch writes */
+#define RFM_MF_NO_WRITER (1 << 30)
 
 typedef struct rfm_ctx rfm_ctx;
 typedef struct rfm_fm_plan rfm_fm_plan;
@@ -212,14 +216,15 @@ int32_t rfm_mf_sgd_levels(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d
                           int32_t n_factors, double lr, double reg);
 
 /* The same schedule in the form the fast kernels read: the batch's examples as
- * 24-byte records {int32 user, int32 item, int32 cache_slot, int32 early, double
+ * 24-byte records {int32 user, int32 item, int32 cache_slot, int32 gap, double
  * label/propensity} grouped by level (ascending batch position inside a level).
  * h_users/h_items/h_y/h_pscore are the batch in batch order.  Up to cache_cap items
  * that occur more than once in the batch (most frequent first) are listed in
  * h_cache_items: the sequential kernel keeps their rows in LDS (cache_slot >= 0;
- * -1 = the item occurs once, -2 = repeated without a slot); early = 1 when the
- * user row's previous writer lies at least three levels back, so the row may be
- * fetched ahead.  Capacities: h_ex batch records, h_level_ptr batch+1,
+ * -1 = the item occurs once, -2 = repeated without a slot); gap = levels between the
+ * example and the previous writer of its user row (RFM_MF_NO_WRITER if none), i.e.
+ * how far ahead of its level the row is final and may be read.  The cached rows must
+ * fit 32 KiB: cache_cap <= 32768 / (8 * (n_factors + 2)).  Capacities: h_ex batch records, h_level_ptr batch+1,
  * h_cache_items cache_cap. */
 int32_t rfm_mf_schedule_ex(const int32_t* h_users, const int32_t* h_items, const double* h_y,
                            const double* h_pscore, int64_t batch, int32_t n_users,
@@ -227,7 +232,7 @@ int32_t rfm_mf_schedule_ex(const int32_t* h_users, const int32_t* h_items, const
                            int32_t* h_level_ptr, int32_t* h_n_levels, int32_t* h_cache_items,
                            int32_t* h_n_cached);
 /* rfm_mf_sgd_levels on those records (d_ex = device copy of h_ex, d_cache_items of
- * h_cache_items; n_cached rows of n_factors+2 doubles must fit 64 KiB of LDS). */
+ * h_cache_items; n_cached rows of n_factors+2 doubles must fit 32 KiB of LDS). */
 int32_t rfm_mf_sgd_levels_ex(rfm_ctx* ctx, const void* d_ex, const int32_t* h_level_ptr,
                              const int32_t* d_level_ptr, int32_t n_levels,
                              const int32_t* d_cache_items, int32_t n_cached, double* d_P,

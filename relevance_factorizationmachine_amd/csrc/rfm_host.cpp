@@ -179,7 +179,7 @@ int32_t rfm_mf_schedule(const int32_t* h_users, const int32_t* h_items, int64_t 
 
 // the level-ordered record of rfm_mf.hip (MfEx)
 struct HostMfEx {
-  int32_t u, i, cslot, early;
+  int32_t u, i, cslot, gap;
   double ry;
 };
 
@@ -200,7 +200,7 @@ int32_t rfm_mf_schedule_ex(const int32_t* h_users, const int32_t* h_items, const
       cnt_i.assign(size_t(n_items), 0);
       slot_i.assign(size_t(n_items), -1);
     }
-    std::vector<int32_t> level(static_cast<size_t>(batch), 0), early(static_cast<size_t>(batch), 0);
+    std::vector<int32_t> level(static_cast<size_t>(batch), 0), gap(static_cast<size_t>(batch), 0);
     int32_t n_levels = 0;
     bool bad = false;
     for (int64_t s = 0; s < batch; ++s) {
@@ -211,8 +211,9 @@ int32_t rfm_mf_schedule_ex(const int32_t* h_users, const int32_t* h_items, const
       }
       const int32_t lv = std::max(last_u[u], last_i[i]) + 1;
       level[size_t(s)] = lv;
-      // the user row is final three levels before lv (or was never written in this batch)
-      early[size_t(s)] = (last_u[u] < 0 || lv - last_u[u] >= 3) ? 1 : 0;
+      // levels back to the previous writer of the user row: the row is final, and may be
+      // read, that far ahead of lv
+      gap[size_t(s)] = last_u[u] < 0 ? RFM_MF_NO_WRITER : lv - last_u[u];
       last_u[u] = lv;
       last_i[i] = lv;
       cnt_i[i]++;
@@ -246,7 +247,7 @@ int32_t rfm_mf_schedule_ex(const int32_t* h_users, const int32_t* h_items, const
         const int32_t i = h_items[s];
         const int32_t cs = cnt_i[i] >= 2 ? slot_i[i] : -1;  // -2: repeated, no slot
         ex[cnt[size_t(level[size_t(s)])]++] =
-            HostMfEx{h_users[s], i, cs, early[size_t(s)], h_y[s] / h_pscore[s]};
+            HostMfEx{h_users[s], i, cs, gap[size_t(s)], h_y[s] / h_pscore[s]};
       }
     }
     // reset only what this batch touched

@@ -19,7 +19,10 @@
 namespace rfm {
 
 constexpr int kMfBlock = 256;
-constexpr int kSeqBlock = 1024;
+#ifndef RFM_SEQ_BLOCK
+#define RFM_SEQ_BLOCK 1024
+#endif
+constexpr int kSeqBlock = RFM_SEQ_BLOCK;  // threads of the sequential workgroup
 constexpr double kMfLogitClip = 700.0;  // src/base.py:65
 
 // Sum over the LPR lanes of a lane group; every lane gets the total.  The steps
@@ -256,7 +259,8 @@ struct MfEx {       // one example of a batch, stored in level order, 24 B
   int32_t u, i;     // user, item
   int32_t cslot;    // >= 0: LDS cache slot of the item row in the sequential kernel;
                     // -1: the item occurs once in the batch; -2: repeated but not cached
-  int32_t early;    // 1: the user row is final three levels before this example runs
+  int32_t gap;      // levels between this example and the previous writer of its user row
+                    // (RFM_MF_NO_WRITER if none in the batch): the row is final that far ahead
   double ry;        // label / propensity
 };
 
@@ -264,6 +268,7 @@ struct MfExArgs {
   const MfEx* ex;            // [batch], grouped by level
   const int32_t* level_ptr;  // device copy (sequential kernel only)
   int32_t lo, hi;            // wide kernel: ex[lo, hi); seq kernel: levels [lo, hi)
+  int32_t rec_lo, rec_hi;    // seq kernel: level_ptr[lo], level_ptr[hi]
   const int32_t* cache_items;  // items whose rows the sequential kernel keeps in LDS
   int32_t n_cached;
   double* P;
@@ -349,127 +354,168 @@ __global__ __launch_bounds__(kMfBlock) void mf_sgd_wide_ex_kernel(MfExArgs a) {
   }
 }
 
-// rows of one example held in registers ahead of its level
+// ---------------------------------------------------------------------------
+// The chain of small levels (the path through a popular item is hundreds of levels
+// long), by ONE workgroup with a barrier between levels.  Nothing on the
+// level-to-level path waits for an index load:
+//  * the chunk's level pointers and example records are copied to LDS first;
+//  * the rows (and biases) of the items that occur more than once in the batch
+//    live in LDS for the whole launch;
+//  * a lane group knows the example it runs kMfAhead levels ahead and loads the
+//    user row / bias (when final by then: MfEx.gap) and the row of an item that
+//    occurs only once into a register slot of a ring of kMfAhead slots.  The ring
+//    is unrolled with fixed slots and its loads are unconditional (unused ones read
+//    row 0).
+// What remains per level (about 0.7 us) is the dependent arithmetic of one example --
+// dot product, lane-group reduction, exp, division, the two row updates -- issued by a
+// single wavefront; a one-wavefront variant without barriers, with an LDS ring that
+// forwards rows between levels, measured no faster and was dropped.
+// ---------------------------------------------------------------------------
+constexpr int kMfAhead = RFM_MF_READ_AHEAD;
+static_assert(kMfAhead == 4, "the level loop below is unrolled for four slots");
+constexpr int kSeqMaxLevels = 1024;  // per launch: level pointers, 4 KiB of LDS
+constexpr int kSeqMaxRecs = 1024;    // per launch: example records, 24 KiB of LDS
+constexpr int kSeqMaxCacheBytes = 32 << 10;
+
 template <int VEC, int NC>
-struct MfRegs {
+struct MfSlot {
+  MfEx e;
+  bool has;       // this lane group has an example at the slot's level
+  bool got_user;  // pp / bu hold the user row (final)
+  bool got_item;  // pq / bi hold the item row (an item that occurs once in the batch)
   MfPack<VEC> pp[NC], pq[NC];
   double bu, bi;
-  bool got_user;  // pp / bu are loaded (and final)
 };
 
-// the example lane group g runs at level `lev` (false: none)
-__device__ __forceinline__ bool mf_fetch_ex(const MfExArgs& a, int lev, int g, MfEx& e) {
-  if (lev >= a.hi) return false;
-  const int32_t idx = a.level_ptr[lev] + g;
-  if (idx >= a.level_ptr[lev + 1]) return false;
-  e = a.ex[idx];
-  return true;
+struct MfSeqLds {
+  const int32_t* lptr;  // [n_lev + 1], relative to the chunk's first record
+  const MfEx* exs;      // [n_rec]
+  double* qcache;       // [n_cached][k+2]: item row, item bias, pad
+  int32_t n_lev;
+};
+
+// what lane group g runs at chunk level t, and its rows if they may be read now: the
+// user row is final when its previous writer lies more than `ahead` levels back
+template <int LPR, int VEC, int NC, bool PF>
+__device__ __forceinline__ void mf_slot_fetch(const MfExArgs& a, const MfSeqLds& m, int t, int g,
+                                              int l, int ahead, MfSlot<VEC, NC>& s) {
+  int32_t idx = 0;
+  bool has = false;
+  if (t < m.n_lev) {
+    idx = m.lptr[t] + g;
+    has = idx < m.lptr[t + 1];
+  }
+  s.e = m.exs[has ? idx : 0];
+  s.has = has;
+  s.got_user = PF && has && s.e.gap > ahead;
+  s.got_item = PF && has && s.e.cslot == -1;
+  if (PF) {
+    const int k = a.k;
+    const int32_t u = s.got_user ? s.e.u : 0;
+    const int32_t it = s.got_item ? s.e.i : 0;
+    mf_load_row<LPR, VEC, NC>(s.pp, a.P + int64_t(u) * k, k, l);
+    s.bu = a.bu[u];
+    mf_load_row<LPR, VEC, NC>(s.pq, a.Q + int64_t(it) * k, k, l);
+    s.bi = a.bi[it];
+  }
 }
 
-// what may be read ahead of the example's level: the user row if final by now,
-// the item row if it is not one of the LDS-cached ones (then it occurs once)
 template <int LPR, int VEC, int NC>
-__device__ __forceinline__ void mf_fetch_rows(const MfExArgs& a, const MfEx& e, bool user_final,
-                                              MfRegs<VEC, NC>& r, int l) {
+__device__ __forceinline__ void mf_slot_run(const MfExArgs& a, const MfSeqLds& m, int l,
+                                            MfSlot<VEC, NC>& s) {
+  if (!s.has) return;
   const int k = a.k;
-  r.got_user = user_final;
-  if (user_final) {
-    mf_load_row<LPR, VEC, NC>(r.pp, a.P + int64_t(e.u) * k, k, l);
-    r.bu = a.bu[e.u];
+  const MfEx e = s.e;
+  if (!s.got_user) {  // written within the last kMfAhead levels: read it now
+    mf_load_row<LPR, VEC, NC>(s.pp, a.P + int64_t(e.u) * k, k, l);
+    s.bu = a.bu[e.u];
   }
-  if (e.cslot == -1) {
-    mf_load_row<LPR, VEC, NC>(r.pq, a.Q + int64_t(e.i) * k, k, l);
-    r.bi = a.bi[e.i];
+  if (e.cslot < 0 && !s.got_item) {  // item row through memory
+    mf_load_row<LPR, VEC, NC>(s.pq, a.Q + int64_t(e.i) * k, k, l);
+    s.bi = a.bi[e.i];
+  }
+  double* crow = m.qcache + (e.cslot >= 0 ? e.cslot : 0) * (k + 2);
+  if (e.cslot >= 0) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int f = (c * LPR + l) * VEC;
+      s.pq[c].load(crow + (f < k ? f : 0));
+    }
+    s.bi = crow[k];
+  }
+  mf_update<LPR, VEC, NC>(s.pp, s.pq, s.bu, s.bi, e.ry, a.b, a.lr, a.reg, k, l);
+  mf_store_row<LPR, VEC, NC>(s.pp, a.P + int64_t(e.u) * k, k, l);
+  if (l == 0) a.bu[e.u] = s.bu;
+  if (e.cslot >= 0) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int f = (c * LPR + l) * VEC;
+      if (f < k) s.pq[c].store(crow + f);
+    }
+    if (l == 0) crow[k] = s.bi;
+  } else {
+    mf_store_row<LPR, VEC, NC>(s.pq, a.Q + int64_t(e.i) * k, k, l);
+    if (l == 0) a.bi[e.i] = s.bi;
   }
 }
 
-// Levels [lo, hi), each of at most kSeqBlock/LPR examples, by ONE workgroup with a
-// barrier between levels.  What makes a level short (the chain through a popular
-// item is hundreds of levels long):
-//  * the rows (and biases) of the items that occur more than once in the batch
-//    live in LDS for the whole launch, so the chain never goes through L2;
-//  * a lane group knows the examples it will run up to three levels ahead and
-//    fetches an example's user row, user bias and (uncached) item row two levels
-//    before it runs, whenever the user row is final by then (MfEx.early: its
-//    previous writer is at least three levels back; an uncached item occurs once
-//    in the batch, so its row is always final).
+// levels [lo, hi) (at most kSeqMaxLevels, kSeqMaxRecs examples, each level of at most
+// kSeqBlock/LPR examples); a.rec_lo / a.rec_hi = level_ptr[lo] / level_ptr[hi]
 template <int LPR, int VEC, int NC>
 __global__ __launch_bounds__(kSeqBlock) void mf_sgd_seq_ex_kernel(MfExArgs a) {
-  extern __shared__ double qcache[];  // [n_cached][k+2]: item row, item bias, pad
+  extern __shared__ double seq_lds[];
+  // rows wider than one chunk per lane leave no registers for a ring of them
+  constexpr bool PF = NC <= 1;
   const int l = threadIdx.x % LPR;
   const int g = threadIdx.x / LPR;
   const int k = a.k;
   const int cw = k + 2;
+  const int n_lev = a.hi - a.lo;
+  const int n_rec = a.rec_hi - a.rec_lo;
+  int32_t* lptr = reinterpret_cast<int32_t*>(seq_lds);
+  MfEx* exs = reinterpret_cast<MfEx*>(seq_lds + (n_lev + 2) / 2);
+  double* qcache = reinterpret_cast<double*>(exs + n_rec);
+  for (int i = threadIdx.x; i <= n_lev; i += kSeqBlock) lptr[i] = a.level_ptr[a.lo + i] - a.rec_lo;
+  {
+    const double* src = reinterpret_cast<const double*>(a.ex + a.rec_lo);
+    double* dst = reinterpret_cast<double*>(exs);
+    for (int i = threadIdx.x; i < n_rec * int(sizeof(MfEx) / 8); i += kSeqBlock) dst[i] = src[i];
+  }
   for (int i = threadIdx.x; i < a.n_cached * cw; i += kSeqBlock) {
     const int c = i / cw, f = i % cw;
     const int32_t item = a.cache_items[c];
     qcache[i] = f < k ? a.Q[int64_t(item) * k + f] : (f == k ? a.bi[item] : 0.0);
   }
-
-  // pipeline per lane group: A runs at this level, B at the next, C the one after.
-  // Rows are held ahead in registers only for factor counts that leave room (NC <= 2);
-  // wider rows are read when their level starts.
-  constexpr bool PF = NC <= 2;
-  MfEx eA{}, eB{}, eC{};
-  MfRegs<VEC, NC> rA, rB, rC;
-  rA.got_user = rB.got_user = rC.got_user = false;
-  bool hA = mf_fetch_ex(a, a.lo, g, eA);
-  bool hB = mf_fetch_ex(a, a.lo + 1, g, eB);
-  bool hC = mf_fetch_ex(a, a.lo + 2, g, eC);
-  // every level before lo has run: A's rows are final; B's only if marked early
-  if (PF && hA) mf_fetch_rows<LPR, VEC, NC>(a, eA, true, rA, l);
-  if (PF && hB) mf_fetch_rows<LPR, VEC, NC>(a, eB, eB.early != 0, rB, l);
   __syncthreads();
+  const MfSeqLds m{lptr, exs, qcache, n_lev};
 
-  for (int lev = a.lo; lev < a.hi; ++lev) {
-    MfEx eD{};
-    const bool hD = mf_fetch_ex(a, lev + 3, g, eD);
-    if (PF && hC) mf_fetch_rows<LPR, VEC, NC>(a, eC, eC.early != 0, rC, l);
-    if (hA) {
-      if (!PF || !rA.got_user) {  // written one or two levels ago: read it now
-        mf_load_row<LPR, VEC, NC>(rA.pp, a.P + int64_t(eA.u) * k, k, l);
-        rA.bu = a.bu[eA.u];
-      }
-      if (eA.cslot == -2 || (!PF && eA.cslot == -1)) {  // item row through memory
-        mf_load_row<LPR, VEC, NC>(rA.pq, a.Q + int64_t(eA.i) * k, k, l);
-        rA.bi = a.bi[eA.i];
-      }
-      double* crow = qcache + (eA.cslot >= 0 ? eA.cslot : 0) * cw;
-      if (eA.cslot >= 0) {
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const int f = (c * LPR + l) * VEC;
-          rA.pq[c].load(crow + (f < k ? f : 0));
-        }
-        rA.bi = crow[k];
-      }
-      mf_update<LPR, VEC, NC>(rA.pp, rA.pq, rA.bu, rA.bi, eA.ry, a.b, a.lr, a.reg, k, l);
-      mf_store_row<LPR, VEC, NC>(rA.pp, a.P + int64_t(eA.u) * k, k, l);
-      if (l == 0) a.bu[eA.u] = rA.bu;
-      if (eA.cslot >= 0) {
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const int f = (c * LPR + l) * VEC;
-          if (f < k) rA.pq[c].store(crow + f);
-        }
-        if (l == 0) crow[k] = rA.bi;
-      } else {
-        mf_store_row<LPR, VEC, NC>(rA.pq, a.Q + int64_t(eA.i) * k, k, l);
-        if (l == 0) a.bi[eA.i] = rA.bi;
-      }
-    }
+  MfSlot<VEC, NC> s0, s1, s2, s3;
+  // every level before lo has run, so the first level's rows are final; a row of one
+  // of the next levels is final if its previous writer lies before this launch
+  mf_slot_fetch<LPR, VEC, NC, PF>(a, m, 0, g, l, 0, s0);
+  mf_slot_fetch<LPR, VEC, NC, PF>(a, m, 1, g, l, 1, s1);
+  mf_slot_fetch<LPR, VEC, NC, PF>(a, m, 2, g, l, 2, s2);
+  mf_slot_fetch<LPR, VEC, NC, PF>(a, m, 3, g, l, 3, s3);
+  for (int t = 0; t < n_lev; t += kMfAhead) {
+    // the rows of level t+4 are read while level t is still running: final if the
+    // previous writer lies before level t, i.e. more than four levels back
+    mf_slot_run<LPR, VEC, NC>(a, m, l, s0);
+    mf_slot_fetch<LPR, VEC, NC, PF>(a, m, t + 4, g, l, kMfAhead, s0);
     __syncthreads();
-    eA = eB;
-    hA = hB;
-    eB = eC;
-    hB = hC;
-    eC = eD;
-    hC = hD;
-    if (PF) {
-      rA = rB;
-      rB = rC;
-    }
+    if (t + 1 >= n_lev) break;
+    mf_slot_run<LPR, VEC, NC>(a, m, l, s1);
+    mf_slot_fetch<LPR, VEC, NC, PF>(a, m, t + 5, g, l, kMfAhead, s1);
+    __syncthreads();
+    if (t + 2 >= n_lev) break;
+    mf_slot_run<LPR, VEC, NC>(a, m, l, s2);
+    mf_slot_fetch<LPR, VEC, NC, PF>(a, m, t + 6, g, l, kMfAhead, s2);
+    __syncthreads();
+    if (t + 3 >= n_lev) break;
+    mf_slot_run<LPR, VEC, NC>(a, m, l, s3);
+    mf_slot_fetch<LPR, VEC, NC, PF>(a, m, t + 7, g, l, kMfAhead, s3);
+    __syncthreads();
   }
+  __syncthreads();
   // write the cached item rows back
   for (int i = threadIdx.x; i < a.n_cached * cw; i += kSeqBlock) {
     const int c = i / cw, f = i % cw;
@@ -635,8 +681,9 @@ int32_t rfm_mf_sgd_levels_ex(rfm_ctx* ctx, const void* d_ex, const int32_t* h_le
     RFM_REQUIRE(n_levels >= 0 && n_cached >= 0 && (n_cached == 0 || d_cache_items),
                 "bad schedule");
     const Shape s = shape_for(n_factors);
-    const size_t lds = size_t(n_cached) * size_t(n_factors + 2) * sizeof(double);
-    RFM_REQUIRE(lds <= (64u << 10), "item cache of %d rows does not fit LDS", n_cached);
+    const size_t cache_bytes = size_t(n_cached) * size_t(n_factors + 2) * sizeof(double);
+    RFM_REQUIRE(cache_bytes <= size_t(kSeqMaxCacheBytes),
+                "item cache of %d rows exceeds %d bytes of LDS", n_cached, kSeqMaxCacheBytes);
     MfExArgs a{};
     a.ex = static_cast<const MfEx*>(d_ex);
     a.level_ptr = d_level_ptr;
@@ -668,10 +715,20 @@ int32_t rfm_mf_sgd_levels_ex(rfm_ctx* ctx, const void* d_ex, const int32_t* h_le
 #undef RFM_CALL_WIDE_EX
         ++lev;
       } else {
+        // a chunk of consecutive small levels that fits the kernel's LDS tables
         int end = lev;
-        while (end < n_levels && h_level_ptr[end + 1] - h_level_ptr[end] <= seq_cap) ++end;
+        while (end < n_levels && end - lev < kSeqMaxLevels) {
+          const int c = h_level_ptr[end + 1] - h_level_ptr[end];
+          RFM_REQUIRE(c >= 0, "level_ptr not monotone");
+          if (c > seq_cap || h_level_ptr[end + 1] - h_level_ptr[lev] > kSeqMaxRecs) break;
+          ++end;
+        }
         a.lo = lev;
         a.hi = end;
+        a.rec_lo = h_level_ptr[lev];
+        a.rec_hi = h_level_ptr[end];
+        const size_t lds = size_t((end - lev + 2) / 2) * 8 + size_t(a.rec_hi - a.rec_lo) * sizeof(MfEx) +
+                           cache_bytes;
 #define RFM_CALL_SEQ_EX(L, Vv, N)                                                              \
   hipLaunchKernelGGL((mf_sgd_seq_ex_kernel<L, Vv, N>), dim3(1), dim3(kSeqBlock), lds, ctx->stream, \
                      a)

@@ -113,8 +113,8 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
         keep = []  # device buffers of in-flight iterations
         h_y = np.ascontiguousarray(train["labels"], dtype=np.float64)
         h_p = np.ascontiguousarray(train["pscores"], dtype=np.float64)
-        # item rows the sequential kernel may keep in LDS (48 KiB of rows + bias)
-        cache_cap = int(min(1024, (48 << 10) // ((self.n_factors + 2) * 8)))
+        # item rows the sequential kernel may keep in LDS (32 KiB of rows + bias)
+        cache_cap = int(min(1024, (32 << 10) // ((self.n_factors + 2) * 8)))
 
         ev_frame = ev_pairs = ev_loop = None
         if self.evaluator is not None:

@@ -151,7 +151,7 @@ def mf_schedule(users: np.ndarray, items: np.ndarray, n_users: int, n_items: int
     return order, level_ptr[: n_levels.value + 1].copy()
 
 
-MF_EX_DTYPE = np.dtype([("u", np.int32), ("i", np.int32), ("cslot", np.int32), ("early", np.int32),
+MF_EX_DTYPE = np.dtype([("u", np.int32), ("i", np.int32), ("cslot", np.int32), ("gap", np.int32),
                         ("ry", np.float64)])
 
 

@@ -283,6 +283,28 @@ def test_mf_fit_vs_oracle(rfm, k, batch):
     assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
 
 
+@pytest.mark.parametrize("k,nu,ni,batch", [(4, 5, 3, 600), (16, 3, 1, 300), (128, 7, 2, 400), (33, 2000, 1, 900),
+                                           (200, 50, 2, 300), (16, 1, 500, 700)])
+def test_mf_long_chains_vs_oracle(rfm, k, nu, ni, batch):
+    """Few users and/or items: every level holds a handful of examples, user rows are
+    rewritten within a few levels (so they cannot be read ahead) and the chain of levels is
+    as long as the batch."""
+    pkg = rfm[0]
+    rng = np.random.default_rng(k + nu)
+    def log(m):
+        pairs = np.stack([rng.integers(0, nu, size=m), rng.integers(0, ni, size=m)], axis=1).astype(np.int64)
+        return {"features": pairs, "labels": (rng.random(m) < 0.5).astype(np.int64),
+                "pscores": rng.uniform(0.1, 1.0, size=m) ** 0.5}
+    train, val = log(1000), log(200)
+    kw = dict(n_epochs=2, n_factors=k, lr=0.005, batch_size=batch, seed=3, n_users=nu, n_items=ni, reg=0.5)
+    model = pkg.LogisticMatrixFactorization(estimator="IPS", **kw)
+    tr, va = model.fit(train, val)
+    ref = cpu_ref.mf_fit(train, val, **kw)
+    for nm in ("P", "Q", "b_u", "b_i"):
+        assert rel_err(getattr(model, nm)(), ref[nm]) < TIGHT, nm
+    assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
+
+
 def test_mf_hogwild_is_a_labelled_non_parity_mode(rfm):
     """HOGWILD updates race on shared users/items (updates of a popular item are
     lost), so it learns more slowly than the sequential result and its parameters

@@ -99,7 +99,7 @@ def test_mf_schedule_edges():
 @pytest.mark.parametrize("seed,cap", [(0, 0), (1, 5), (2, 1000)])
 def test_mf_schedule_ex_records(seed, cap):
     """Level-ordered records: same levels as the plain schedule, label/propensity
-    ratio, item cache slots for the most frequent repeated items, 'early' flags."""
+    ratio, item cache slots for the most frequent repeated items, gap to the user row's previous writer."""
     rng = np.random.default_rng(seed)
     b, nu, ni = 2500, 400, 90
     users = rng.integers(0, nu, size=b)
@@ -123,9 +123,9 @@ def test_mf_schedule_ex_records(seed, cap):
     early_ref = np.zeros(b, dtype=np.int32)
     for s in range(b):
         pu = last_u.get(users[s], None)
-        early_ref[s] = 1 if pu is None or lev[s] - pu >= 3 else 0
+        early_ref[s] = (1 << 30) if pu is None else lev[s] - pu  # RFM_MF_NO_WRITER
         last_u[users[s]] = lev[s]
-    np.testing.assert_array_equal(ex["early"], early_ref[order])
+    np.testing.assert_array_equal(ex["gap"], early_ref[order])
     for rec in ex:
         it = int(rec["i"])
         want = slot_of.get(it, -1 if counts[it] == 1 else -2)

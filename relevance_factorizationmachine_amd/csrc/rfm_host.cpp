@@ -78,11 +78,22 @@ static void sample_one(int64_t n_rows, int64_t batch, uint32_t seed, int32_t* sc
                        int32_t* out) {
   for (int64_t i = 0; i < n_rows; ++i) scratch[i] = int32_t(i);
   Mt19937 rng(seed);
-  for (int64_t i = n_rows - 1; i >= 1; --i) {
-    uint32_t j = rng.interval(uint32_t(i));
-    int32_t tmp = scratch[i];
-    scratch[i] = scratch[j];
-    scratch[j] = tmp;
+  // the draws do not depend on the array, so a block of swap partners is drawn (and
+  // their cache lines requested) before the block's swaps are done, in the same order
+  constexpr int kBlock = 32;
+  uint32_t js[kBlock];
+  for (int64_t i = n_rows - 1; i >= 1;) {
+    const int cnt = int(std::min<int64_t>(kBlock, i));
+    for (int c = 0; c < cnt; ++c) {
+      js[c] = rng.interval(uint32_t(i - c));
+      __builtin_prefetch(scratch + js[c], 1);
+    }
+    for (int c = 0; c < cnt; ++c) {
+      const int32_t tmp = scratch[i - c];
+      scratch[i - c] = scratch[js[c]];
+      scratch[js[c]] = tmp;
+    }
+    i -= cnt;
   }
   std::memcpy(out, scratch, size_t(batch) * sizeof(int32_t));
 }

@@ -20,7 +20,7 @@ from . import _lib
 from .base import LOSS_EPS, PointwiseBaseRecommender
 from .evaluate import EvalLoop, device_frame
 from .optimizer import DeviceSGD
-from .runtime import CsrCache, DeviceCSR, Runtime, sample_batches
+from .runtime import BatchIdStream, CsrCache, DeviceCSR, Runtime
 
 
 class FmPlan:
@@ -111,8 +111,9 @@ class FactorizationMachines(PointwiseBaseRecommender):
             raise ValueError(f"train features have {X.shape[1]} columns, model has {self.n_features}")
         if self.n_epochs <= 0:
             return [], []
-        # batch selection: resample(..., random_state=epoch) (src/fm.py:72-79)
-        ids = sample_batches(n_rows, self.batch_size, 0, self.n_epochs)
+        # batch selection: resample(..., random_state=epoch) (src/fm.py:72-79), sampled on the
+        # host chunk by chunk while the GPU trains on the chunk before
+        id_stream = BatchIdStream(rt, n_rows, self.batch_size, self.n_epochs)
 
         tr = DeviceCSR(rt, X)
         y = rt.upload(np.asarray(train["labels"]), dtype=np.float64)
@@ -120,37 +121,30 @@ class FactorizationMachines(PointwiseBaseRecommender):
         va = DeviceCSR(rt, val["features"])
         vy = rt.upload(np.asarray(val["labels"]), dtype=np.float64)
         vp = rt.upload(np.asarray(val["pscores"]), dtype=np.float64)
-        d_ids = rt.upload(ids)
         plan = FmPlan(rt, tr, train["labels"], train["pscores"], self.n_factors, self.batch_size,
                       self.hot_min_count)
         tl = rt.empty((self.n_epochs,), y.dtype)
         vl = rt.empty((self.n_epochs,), y.dtype)
 
+        chunk = {"first": 0, "ids": None}
+
         def run(first: int, count: int) -> None:
+            ids_ptr = chunk["ids"].data_ptr() + (first - chunk["first"]) * self.batch_size * 4
             _lib.check(rt.lib.rfm_fm_train(
                 rt.ctx, plan.handle, tr.indptr.data_ptr(), tr.indices.data_ptr(), tr.values.data_ptr(),
-                y.data_ptr(), p.data_ptr(), d_ids.data_ptr() + first * self.batch_size * 4,
-                self.batch_size, count,
+                y.data_ptr(), p.data_ptr(), ids_ptr, self.batch_size, count,
                 self.w0.dev.data_ptr(), self.w.dev.data_ptr(), self.V.dev.data_ptr(), float(self.lr),
                 va.indptr.data_ptr(), va.indices.data_ptr(), va.values.data_ptr(),
                 vy.data_ptr(), vp.data_ptr(), va.shape[0], LOSS_EPS,
                 tl.data_ptr() + first * 8, vl.data_ptr() + first * 8))
 
         try:
-            if self.evaluator is None:
-                run(0, self.n_epochs)
-            else:
+            frame = loop = ev = ev_X = None
+            if self.evaluator is not None:
                 ev_X = self.evaluator.features[self.model_name]
                 frame = (device_frame(rt, self.evaluator, self.estimator, ev_X.shape[0])
                          if self.device_evaluator else None)
-                if frame is None:
-                    # an evaluator of unknown kind is a host callback: one iteration per enqueue
-                    for epoch in range(self.n_epochs):
-                        run(epoch, 1)
-                        y_scores = self.predict(X=ev_X)
-                        self.val_metrics.append(
-                            self.evaluator.evaluate(y_scores=y_scores, estimator=self.estimator))
-                else:
+                if frame is not None:
                     # ValEvaluator's IPS-DCG@k from the scores in HBM (rfm_val_dcg); only
                     # iterations whose value hangs on the order of tied scores go to the host
                     if ev_X.shape[1] != self.n_features:
@@ -158,7 +152,20 @@ class FactorizationMachines(PointwiseBaseRecommender):
                             f"X has {ev_X.shape[1]} columns, model has {self.n_features}")
                     ev = self._csr_cache.get(ev_X)
                     loop = EvalLoop(rt, frame, self.evaluator, self.estimator, self.n_epochs)
-                    for epoch in range(self.n_epochs):
+            for first, host_ids, dev_ids in id_stream.chunks():
+                chunk["first"], chunk["ids"] = first, dev_ids
+                count = host_ids.shape[0]
+                if self.evaluator is None:
+                    run(first, count)
+                elif frame is None:
+                    # an evaluator of unknown kind is a host callback: one iteration per enqueue
+                    for epoch in range(first, first + count):
+                        run(epoch, 1)
+                        y_scores = self.predict(X=ev_X)
+                        self.val_metrics.append(
+                            self.evaluator.evaluate(y_scores=y_scores, estimator=self.estimator))
+                else:
+                    for epoch in range(first, first + count):
                         run(epoch, 1)
                         _lib.check(rt.lib.rfm_fm_forward(
                             rt.ctx, ev.indptr.data_ptr(), ev.indices.data_ptr(), ev.values.data_ptr(),
@@ -166,8 +173,9 @@ class FactorizationMachines(PointwiseBaseRecommender):
                             self.V.dev.data_ptr(), self.n_features, self.n_factors,
                             loop.slot(epoch).data_ptr()))
                         loop.done(epoch)
-                    self.val_metrics.extend(loop.finish(self.n_epochs))
-                    self.evaluator_host_calls = loop.host_calls
+            if loop is not None:
+                self.val_metrics.extend(loop.finish(self.n_epochs))
+                self.evaluator_host_calls = loop.host_calls
             rt.sync()
         finally:
             rt.sync()

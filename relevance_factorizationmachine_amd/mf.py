@@ -18,7 +18,7 @@ from . import _lib
 from .base import LOSS_EPS, PointwiseBaseRecommender
 from .evaluate import EvalLoop, device_frame
 from .optimizer import DeviceSGD
-from .runtime import Runtime, mf_schedule_ex, sample_batches
+from .runtime import BatchIdStream, Runtime, mf_schedule_ex
 
 
 class DevicePairs:
@@ -94,7 +94,9 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
         n_rows = int(np.asarray(train["features"]).shape[0])
         if self.n_epochs <= 0:
             return [], []
-        ids = sample_batches(n_rows, self.batch_size, 0, self.n_epochs)
+        # resample(..., random_state=epoch) ids (src/mf.py:88-95), sampled chunk by chunk on
+        # the host while the GPU works on the chunk before
+        id_stream = BatchIdStream(rt, n_rows, self.batch_size, self.n_epochs)
 
         tr = DevicePairs(rt, train["features"])
         va = DevicePairs(rt, val["features"])
@@ -104,7 +106,6 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
         p = rt.upload(np.asarray(train["pscores"]), dtype=np.float64)
         vy = rt.upload(np.asarray(val["labels"]), dtype=np.float64)
         vp = rt.upload(np.asarray(val["pscores"]), dtype=np.float64)
-        d_ids = rt.upload(ids)
         tl = rt.empty((self.n_epochs,), y.dtype)
         vl = rt.empty((self.n_epochs,), y.dtype)
         params = (self.P.dev.data_ptr(), self.Q.dev.data_ptr(), self.b_u.dev.data_ptr(),
@@ -127,9 +128,7 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
                 self._check_ids(ev_pairs)
                 ev_loop = EvalLoop(rt, ev_frame, self.evaluator, self.estimator, self.n_epochs)
 
-        for epoch in range(self.n_epochs):
-            rows = ids[epoch]
-            ids_ptr = d_ids.data_ptr() + epoch * self.batch_size * 4
+        for epoch, rows, ids_ptr in self._epochs(id_stream):
             if self.hogwild:
                 _lib.check(rt.lib.rfm_mf_sgd_hogwild(
                     rt.ctx, tr.users.data_ptr(), tr.items.data_ptr(), y.data_ptr(), p.data_ptr(),
@@ -172,6 +171,12 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
             self.val_metrics.extend(ev_loop.finish(self.n_epochs))
             self.evaluator_host_calls = ev_loop.host_calls
         return tl.cpu().numpy().tolist(), vl.cpu().numpy().tolist()
+
+    def _epochs(self, id_stream: BatchIdStream):
+        """``(epoch, host row ids, device address of the ids)`` of every iteration."""
+        for first, host_ids, dev_ids in id_stream.chunks():
+            for j in range(host_ids.shape[0]):
+                yield first + j, host_ids[j], dev_ids.data_ptr() + j * self.batch_size * 4
 
     # -------------------------------------------------------------- predict
     def predict(self, X) -> np.ndarray:

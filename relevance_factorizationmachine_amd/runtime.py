@@ -137,6 +137,35 @@ def sample_batches(n_rows: int, batch_size: int, epoch_begin: int, n_epochs: int
     return out
 
 
+class BatchIdStream:
+    """The row-id lists of a whole ``fit()`` in chunks of iterations: a chunk is sampled
+    on the host (``rfm_sample_batches``, exact ``resample`` ids) while the GPU works on the
+    chunk before it, and uploaded when that one has been enqueued (the
+    Mersenne-Twister shuffle is inherently sequential per iteration, so it stays on the host
+    cores -- one iteration per thread -- and is overlapped rather than moved)."""
+
+    CHUNK_IDS = 1 << 23  # ids per chunk: 32 MiB of int32
+
+    def __init__(self, rt: Runtime, n_rows: int, batch_size: int, n_epochs: int):
+        self.rt, self.n_rows, self.batch_size, self.n_epochs = rt, n_rows, batch_size, n_epochs
+        self.chunk = int(max(1, min(max(n_epochs, 1), self.CHUNK_IDS // max(batch_size, 1))))
+        # the first chunk now: a batch larger than the log raises before anything is uploaded
+        self._host = sample_batches(n_rows, batch_size, 0, min(self.chunk, n_epochs))
+
+    def chunks(self):
+        """Yields ``(first_epoch, host_ids (count, B), device_ids)``; the next chunk is
+        sampled after the consumer has enqueued the work of the current one."""
+        first = 0
+        while first < self.n_epochs:
+            host = self._host
+            dev = self.rt.upload(host)
+            yield first, host, dev
+            first += host.shape[0]
+            if first < self.n_epochs:
+                self._host = sample_batches(self.n_rows, self.batch_size, first,
+                                            min(self.chunk, self.n_epochs - first))
+
+
 def mf_schedule(users: np.ndarray, items: np.ndarray, n_users: int, n_items: int):
     """Level schedule of one batch: ``(order int32[B], level_ptr int32[L+1])``."""
     lib = _lib.load()

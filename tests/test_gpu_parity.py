@@ -85,6 +85,37 @@ def test_mf_fit_matches_reference_golden(rfm, est):
     assert rel_err(model.predict(val["features"]), g[f"{est}_pred_val"]) < TIGHT
 
 
+def test_fit_with_ids_sampled_in_chunks(rfm):
+    """The row-id lists arrive in chunks of iterations (sampled while the GPU works on the
+    chunk before): three iterations per chunk here, same result as the reference's fit."""
+    pkg, _lib, runtime, rt = rfm
+    old = runtime.BatchIdStream.CHUNK_IDS
+    try:
+        for fixture, shape, cls in (("fm_coat_k8", "coat", "FM"), ("mf_small", "kuairec_small", "MF")):
+            g = load_golden(fixture)
+            sh = synth.SHAPES[shape]
+            train, val = synth.make_log(sh, cls, "IPS", seed=0)
+            runtime.BatchIdStream.CHUNK_IDS = 3 * sh.batch_size
+            if cls == "FM":
+                model = pkg.FactorizationMachines(
+                    estimator="IPS", n_epochs=int(g["n_epochs"]), n_factors=sh.n_factors,
+                    n_features=train["features"].shape[1], lr=float(g["IPS_lr"]), batch_size=sh.batch_size,
+                    seed=int(g["seed"]))
+                names = ("V", "w")
+            else:
+                runtime.BatchIdStream.CHUNK_IDS = 2 * sh.batch_size  # three iterations: chunks of 2 + 1
+                model = pkg.LogisticMatrixFactorization(
+                    estimator="IPS", n_epochs=3, n_factors=16, n_users=sh.n_users, n_items=sh.n_items,
+                    lr=0.01, reg=0.5, batch_size=2000, seed=12345)
+                names = ("P", "Q", "b_u", "b_i")
+            tr, va = model.fit(train, val)
+            for nm in names:
+                assert rel_err(getattr(model, nm)(), g[f"IPS_{nm}"]) < TIGHT, (fixture, nm)
+            assert rel_err(tr, g["IPS_train_loss"]) < TIGHT and rel_err(va, g["IPS_val_loss"]) < TIGHT
+    finally:
+        runtime.BatchIdStream.CHUNK_IDS = old
+
+
 def test_dcg_parity_on_gpu_scores(rfm):
     """DCG@5 of the GPU's validation scores equals the reference's (fixture G7)."""
     pkg = rfm[0]

@@ -172,6 +172,17 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = K * gB / elapsed
+    in_sync = None
+    if world > 1:
+        # outside the timed region: every replica must hold the same parameters
+        chk = torch.stack([model.V.dev.sum(), model.w.dev.sum(), model.w0.dev.sum()]).to(
+            "cuda" if args.backend == "nccl" else "cpu")
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool(torch.equal(lo, hi)) and bool(torch.isfinite(chk).all())
+        if not in_sync:
+            print(f"[rank {rank}] replicas diverged: {lo.tolist()} vs {hi.tolist()}", file=sys.stderr)
 
     out = {
         "metric": "training examples/sec (FM, k=32)",
@@ -196,6 +207,7 @@ def main() -> None:
             "parallelism": f"dp{world}" if world > 1 else "single",
             "collective": (f"all-reduce(sum) of the dense [G_V|g_w|g_w0] buffer, {8 * (n * (k + 1) + 1) / 1e6:.1f} MB, "
                            f"{transport}") if world > 1 else None,
+            "replicas_in_sync": in_sync,
         },
     }
 

@@ -141,6 +141,17 @@ void forward_loss(rfm_ctx* ctx, FwdArgs a, double* d_out_loss) {
   RFM_HIP_CHECK(hipGetLastError());
 }
 
+// forward with loss whose partials go to `partial_row` (kMaxFwdGrid doubles) and are
+// finished later, many launches at once; returns the number of partials written
+int forward_loss_deferred(rfm_ctx* ctx, FwdArgs a, double* partial_row) {
+  RFM_REQUIRE(a.n_rows > 0, "loss of zero rows");
+  const FwdGeom geom = forward_geom(ctx, a.n_rows, shape_for(a.k), a.ent != nullptr);
+  RFM_REQUIRE(geom.grid <= kMaxFwdGrid, "forward grid %d exceeds %d", geom.grid, kMaxFwdGrid);
+  a.loss_partial = partial_row;
+  launch_forward(ctx, a, geom);
+  return geom.grid;
+}
+
 }  // namespace rfm
 
 // ---------------------------------------------------------------------------
@@ -154,6 +165,7 @@ struct rfm_fm_plan {
   int64_t step = 0;  // stamps the carries of a step
   rfm::DevBuf ent, rows, slot_t, slots, win, cross, carry_idx, carries, Q, err, hot_cols,
       hot_slab, hot_part, err_partial;
+  rfm::DevBuf loss_rows;  // rfm_fm_train: per-workgroup loss partials of a run of iterations
   size_t device_bytes() const {
     return ent.bytes + rows.bytes + slot_t.bytes + slots.bytes + win.bytes + cross.bytes +
            carry_idx.bytes + carries.bytes + Q.bytes + err.bytes + hot_cols.bytes +
@@ -631,8 +643,29 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
       RFM_REQUIRE(d_val_indptr && d_val_indices && d_val_values && d_val_y && d_val_pscore &&
                       n_val >= 1,
                   "validation arrays missing");
+    // the losses' per-workgroup partials of a run of iterations are finished by one launch
+    // per run (fixed order inside an iteration, as loss_finish_kernel does it)
+    constexpr int64_t kRun = 128;
+    if (d_out_train_loss || d_out_val_loss)
+      plan->loss_rows.ensure(size_t(2 * kRun) * size_t(kMaxFwdGrid) * sizeof(double));
+    double* train_rows = plan->loss_rows.as<double>();
+    double* val_rows = train_rows + kRun * kMaxFwdGrid;
+    int train_parts = 0, val_parts = 0;
+    const auto finish = [&](int64_t first, int64_t count) {
+      if (count <= 0) return;
+      if (d_out_train_loss)
+        hipLaunchKernelGGL(loss_finish_many_kernel, dim3(int(count)), dim3(kBlock), 0, ctx->stream,
+                           train_rows, int64_t(kMaxFwdGrid), train_parts, batch,
+                           d_out_train_loss + first);
+      if (d_out_val_loss)
+        hipLaunchKernelGGL(loss_finish_many_kernel, dim3(int(count)), dim3(kBlock), 0, ctx->stream,
+                           val_rows, int64_t(kMaxFwdGrid), val_parts, n_val, d_out_val_loss + first);
+      RFM_HIP_CHECK(hipGetLastError());
+    };
+    int64_t run_first = 0;
     for (int64_t it = 0; it < n_iters; ++it) {
       const int32_t* ids = d_ids + it * batch;
+      const int64_t slot = it - run_first;
       enqueue_step(ctx, plan, d_indptr, d_indices, d_values, d_y, d_pscore, ids, batch, d_w0,
                    d_w, d_V, lr, nullptr);
       if (d_out_train_loss) {
@@ -647,7 +680,7 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
         f.V = d_V;
         f.k = plan->k;
         f.eps = eps;
-        forward_loss(ctx, f, d_out_train_loss + it);
+        train_parts = forward_loss_deferred(ctx, f, train_rows + slot * kMaxFwdGrid);
       }
       if (d_out_val_loss) {
         FwdArgs f = forward_args(d_val_indptr, d_val_indices, d_val_values, nullptr, n_val,
@@ -655,9 +688,14 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
         f.y = d_val_y;
         f.pscore = d_val_pscore;
         f.eps = eps;
-        forward_loss(ctx, f, d_out_val_loss + it);
+        val_parts = forward_loss_deferred(ctx, f, val_rows + slot * kMaxFwdGrid);
+      }
+      if (slot + 1 == kRun) {
+        finish(run_first, kRun);
+        run_first = it + 1;
       }
     }
+    finish(run_first, n_iters - run_first);
   });
 }
 

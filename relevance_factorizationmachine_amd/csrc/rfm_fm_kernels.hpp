@@ -428,6 +428,18 @@ __global__ __launch_bounds__(kBlock) void loss_finish_kernel(const double* parti
   if (threadIdx.x == 0) out[0] = -s / double(n_rows);
 }
 
+// the same for a run of launches at once: block b finishes the partials of launch b
+__global__ __launch_bounds__(kBlock) void loss_finish_many_kernel(const double* partial,
+                                                                 int64_t stride, int n_partial,
+                                                                 int64_t n_rows, double* out) {
+  __shared__ double lds[kBlock];
+  const double* row = partial + int64_t(blockIdx.x) * stride;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_partial; i += kBlock) acc += row[i];
+  const double s = block_sum<kBlock>(acc, lds);
+  if (threadIdx.x == 0) out[blockIdx.x] = -s / double(n_rows);
+}
+
 // standalone IPS log-loss of given scores (src/base.py:37-61)
 __global__ __launch_bounds__(kBlock) void logloss_kernel(const double* y, const double* pred,
                                                         const double* pscore,

@@ -53,17 +53,18 @@ static_assert(RFM_MAX_FACTORS <= 1024, "fm_finalize_kernel's LDS totals hold 102
 
 namespace rfm {
 
-// bytes of LDS a forward workgroup spends on the hot class sums: with the 4 KiB of
-// reduction scratch and the 16.5 KiB entry buffer, two 512-thread workgroups fit a CU
+// bytes of LDS a forward workgroup spends on the hot class sums (next to 8 KiB of
+// reduction scratch and the 33 KiB entry buffer of the 1024-thread shape: gfx950 gives a
+// workgroup up to 160 KiB)
 constexpr size_t kHotLdsBudget = 56 << 10;
 constexpr int kMaxHot = 160;  // beyond this the slab traffic outweighs what the class saves
 
 // slots per window of fm_consume_kernel for a lane-group width (WinShape<LPR>::WIN)
 inline int window_slots(int lpr) { return lpr >= 64 ? 64 : (lpr == 32 ? 64 : 4 * lpr); }
 
-// forward launch geometry: 512-thread workgroups whose lane groups keep several
-// rows in flight once the batch fills the chip with them (two per CU: few
-// hot-sum slabs), 256-thread / one-row ones otherwise.  RFM_FWD_PER_CU
+// forward launch geometry: 1024-thread workgroups whose lane groups keep several
+// rows in flight once the batch fills the chip with them (one per CU: as few
+// hot-sum slabs as possible), 256-thread / one-row ones otherwise.  RFM_FWD_PER_CU
 // overrides the workgroups per CU of the big shape (tuning experiments only).
 struct FwdGeom {
   int block, grid;
@@ -75,13 +76,13 @@ inline int env_int(const char* name, int dflt) {
 }
 
 inline FwdGeom forward_geom(const rfm_ctx* ctx, int64_t n_rows, const Shape& s, bool records) {
-  static const int per_cu = std::max(1, env_int("RFM_FWD_PER_CU", 2));
+  static const int per_cu = std::max(1, env_int("RFM_FWD_PER_CU", kBigBlock >= 1024 ? 1 : 2));
   static const int force = env_int("RFM_FWD_BLOCK", 0);
   FwdGeom g;
-  const int64_t rows_big = int64_t(512 / s.lpr) * rows_in_flight(s.nc);
+  const int64_t rows_big = int64_t(kBigBlock / s.lpr) * rows_in_flight(s.nc);
   const int64_t blocks_big = (n_rows + rows_big - 1) / rows_big;
   if (records && force != 256 && (force == 512 || blocks_big >= int64_t(ctx->n_cu) * per_cu)) {
-    g.block = 512;
+    g.block = kBigBlock;
     g.grid = int(std::max<int64_t>(1, std::min<int64_t>(blocks_big, int64_t(ctx->n_cu) * per_cu)));
   } else {
     g.block = 256;
@@ -104,14 +105,23 @@ void launch_forward(rfm_ctx* ctx, FwdArgs a, FwdGeom geom) {
   if (a.n_rows <= 0) return;
   const Shape s = shape_for(a.k);
   const size_t lds =
-      forward_lds_bytes(geom.block, s.lpr, geom.block == 512 ? rows_in_flight(s.nc) : 1, a.n_hot,
+      forward_lds_bytes(geom.block, s.lpr, geom.block == kBigBlock ? rows_in_flight(s.nc) : 1, a.n_hot,
                         a.k);
 
 #define RFM_CALL_FWD(L, Vv, N)                                                                \
   do {                                                                                        \
-    if (a.ent && geom.block == 512)                                                           \
-      hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, 512, rows_in_flight(N), true>),         \
-                         dim3(geom.grid), dim3(512), lds, ctx->stream, a);                    \
+    if (a.ent && geom.block == kBigBlock) {                                                   \
+      static size_t lds_allowed = 64u << 10; /* per instantiation: raised on demand */       \
+      if (lds > lds_allowed) {                                                                \
+        RFM_HIP_CHECK(hipFuncSetAttribute(                                                    \
+            reinterpret_cast<const void*>(                                                    \
+                &fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), true>),            \
+            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));                           \
+        lds_allowed = lds;                                                                    \
+      }                                                                                       \
+      hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), true>),   \
+                         dim3(geom.grid), dim3(kBigBlock), lds, ctx->stream, a);              \
+    }                                                                                         \
     else if (a.ent)                                                                           \
       hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, 256, 1, true>), dim3(geom.grid),        \
                          dim3(256), lds, ctx->stream, a);                                     \

@@ -101,6 +101,10 @@ struct Pack<2> {
 };
 
 // waves per SIMD the big forward shape is compiled for (register budget 512/N)
+#ifndef RFM_FWD_BIG_BLOCK
+#define RFM_FWD_BIG_BLOCK 1024
+#endif
+constexpr int kBigBlock = RFM_FWD_BIG_BLOCK;  // threads of the forward's many-rows-in-flight shape
 #ifndef RFM_FWD_BIG_WAVES
 #define RFM_FWD_BIG_WAVES 4
 #endif
@@ -167,7 +171,7 @@ struct FwdArgs {
 // caller's CSR arrays.
 // LDS (dynamic): red[BLOCK] f64 | entry buffer [BLOCK/LPR][R*LPR+1] Entry | hot sums [H][k+2] f64
 template <int LPR, int VEC, int NC, int BLOCK, int R, bool REC>
-__global__ __launch_bounds__(BLOCK, (BLOCK == 512 ? RFM_FWD_BIG_WAVES : 1)) void fm_forward_kernel(
+__global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)) void fm_forward_kernel(
     FwdArgs a) {
   constexpr int GPB = BLOCK / LPR;  // lane groups per block
   extern __shared__ double dyn_lds[];

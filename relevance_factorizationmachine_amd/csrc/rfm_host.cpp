@@ -46,30 +46,67 @@ struct Mt19937 {
     pos = 0;
   }
 
+  // refill + temper a whole block at once (two plain loops the compiler vectorises);
+  // `out` then holds the next N outputs of the generator
+  uint32_t out[N];
+  void refill_tempered() {
+    refill();
+    for (int i = 0; i < N; ++i) {
+      uint32_t y = key[i];
+      y ^= y >> 11;
+      y ^= (y << 7) & 0x9d2c5680u;
+      y ^= (y << 15) & 0xefc60000u;
+      y ^= y >> 18;
+      out[i] = y;
+    }
+  }
+
   inline uint32_t next32() {
-    if (pos == N) refill();
-    uint32_t y = key[pos++];
-    y ^= y >> 11;
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= y >> 18;
-    return y;
+    if (pos == N) refill_tempered();
+    return out[pos++];
   }
 
   // NumPy's random_interval for max <= 0xffffffff: mask to the next power of
   // two minus one, redraw while above max.
-  inline uint32_t interval(uint32_t max) {
-    if (max == 0) return 0;
+  static inline uint32_t mask_for(uint32_t max) {
     uint32_t mask = max;
     mask |= mask >> 1;
     mask |= mask >> 2;
     mask |= mask >> 4;
     mask |= mask >> 8;
     mask |= mask >> 16;
+    return mask;
+  }
+  inline uint32_t interval(uint32_t max) {
+    if (max == 0) return 0;
+    const uint32_t mask = mask_for(max);
     uint32_t v;
     while ((v = (next32() & mask)) > max) {
     }
     return v;
+  }
+
+  // interval(max), interval(max-1), ..., `want` of them (want <= max), into dst[0..want)
+  // (dst has room for want+1).  The redraw-while-above-max loop is a coin flip per output
+  // for the branch predictor; here every masked output is stored and the write position
+  // advances by the comparison's result instead, so the only branches are loop bounds.
+  void intervals_down(uint32_t max, int want, uint32_t* dst) {
+    int got = 0;
+    uint32_t cur = max;
+    while (got < want) {
+      if (pos == N) refill_tempered();
+      const uint32_t mask = mask_for(cur);
+      const uint32_t half = mask >> 1;  // the mask holds while cur > half
+      int p = pos;
+      while (p < N && got < want && cur > half) {
+        const uint32_t v = out[p++] & mask;
+        dst[got] = v;
+        const uint32_t ok = v <= cur ? 1u : 0u;
+        got += int(ok);
+        cur -= ok;
+      }
+      pos = p;
+    }
   }
 };
 
@@ -80,14 +117,12 @@ static void sample_one(int64_t n_rows, int64_t batch, uint32_t seed, int32_t* sc
   Mt19937 rng(seed);
   // the draws do not depend on the array, so a block of swap partners is drawn (and
   // their cache lines requested) before the block's swaps are done, in the same order
-  constexpr int kBlock = 32;
-  uint32_t js[kBlock];
+  constexpr int kBlock = 128;
+  uint32_t js[kBlock + 1];
   for (int64_t i = n_rows - 1; i >= 1;) {
     const int cnt = int(std::min<int64_t>(kBlock, i));
-    for (int c = 0; c < cnt; ++c) {
-      js[c] = rng.interval(uint32_t(i - c));
-      __builtin_prefetch(scratch + js[c], 1);
-    }
+    rng.intervals_down(uint32_t(i), cnt, js);
+    for (int c = 0; c < cnt; ++c) __builtin_prefetch(scratch + js[c], 1);
     for (int c = 0; c < cnt; ++c) {
       const int32_t tmp = scratch[i - c];
       scratch[i - c] = scratch[js[c]];

@@ -225,6 +225,30 @@ def test_fm_fit_ragged_logs(rfm, k, batch, dense_cols, hot):
     assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
 
 
+@pytest.mark.parametrize("hot", [0, -1])
+@pytest.mark.parametrize("k,density,dense_cols", [(3, 0.04, 1), (32, 0.25, 4), (33, 0.05, 0), (96, 0.05, 2),
+                                                  (200, 0.03, 1)])
+def test_fm_fit_full_chip_batches(rfm, k, density, dense_cols, hot):
+    """Batches large enough for the forward's many-rows-in-flight shape (one 1024-thread
+    workgroup per CU): odd factor counts, rows longer than one lane group's round of
+    entries (density 0.25 x 120 columns), rows of several chunks per lane (k = 200), with
+    and without the on-chip hot sums.  Two iterations against the oracle."""
+    pkg = rfm[0]
+    rng = np.random.default_rng(7 * k + hot)
+    n_rows, batch, n_cols = 45_000, 40_000, 120
+    train = _random_log(rng, n_rows, n_cols, density, dense_cols)
+    val = _random_log(rng, 400, n_cols, density, dense_cols)
+    lr = 2e-6
+    model = _fm(pkg, n_factors=k, n_features=n_cols, lr=lr, batch_size=batch, n_epochs=2, seed=5)
+    model.hot_min_count = hot
+    tr, va = model.fit(train, val)
+    ref = cpu_ref.fm_fit(train, val, n_epochs=2, n_factors=k, lr=lr, batch_size=batch, seed=5)
+    assert rel_err(model.V(), ref["V"]) < TIGHT
+    assert rel_err(model.w(), ref["w"]) < TIGHT
+    assert rel_err(model.w0(), ref["w0"]) < TIGHT
+    assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
+
+
 def test_non_canonical_csr_inputs(rfm):
     """CSR as SciPy allows it: duplicate column entries inside a row (SciPy sums them
     before squaring -- X.power(2) de-duplicates -- and so must we), unsorted indices,

@@ -130,6 +130,15 @@ def load():
             raise RfmError(
                 f"{LIB_PATH} is missing and hipcc is not available to build it; "
                 "the HIP extension is required (there is no CPU fallback)")
+    # PyTorch supplies the device memory and streams this library works on, and its wheel
+    # ships its own HIP runtime: that runtime has to be in the process BEFORE this library
+    # is mapped, or the loader binds librfm_hip.so to a second, separate runtime (ROCm's
+    # system copy) that knows nothing of torch's allocations -- and, on the GPU boxes, finds
+    # no device.  A process without PyTorch gets the system runtime, as any HIP program.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         lib = C.CDLL(path)
     except OSError as exc:

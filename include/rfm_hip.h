@@ -54,7 +54,6 @@ enum {
 
 typedef struct rfm_ctx rfm_ctx;
 typedef struct rfm_fm_plan rfm_fm_plan;
-typedef struct rfm_mf_sched rfm_mf_sched;
 
 /* ---- diagnostics ------------------------------------------------------- */
 int32_t rfm_version(void);

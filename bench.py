@@ -66,6 +66,9 @@ def main() -> None:
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse "
                          "the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --batch-size is the GLOBAL batch, split over the GPUs "
+                         "(default: weak scaling, --batch-size rows per GPU)")
     ap.add_argument("--no-direct-rccl", action="store_true",
                     help="multi-GPU: exchange through torch.distributed instead of the C ABI's RCCL binding")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -97,6 +100,10 @@ def main() -> None:
     n_train = args.n_train or shape.n_train
     k, B, K, W = shape.n_factors, args.batch_size, args.steps, args.warmup
     lr, seed = 9e-6, 12345  # conf/setting/kuairec.yaml: FM/IPS lr, seed
+    if args.strong:
+        if B % world:
+            raise SystemExit(f"--strong: global batch {B} is not a multiple of {world} GPUs")
+        B //= world
     gB = B * world
     if gB > n_train:
         raise SystemExit(f"global batch {gB} exceeds the log ({n_train} rows)")
@@ -193,7 +200,7 @@ def main() -> None:
         "warmup": W,
         "ms_per_step": 1e3 * elapsed / K,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",

@@ -1,0 +1,73 @@
+"""Randomised parity (hypothesis): small FM and MF fits of arbitrary shape against the
+oracle, through the C ABI.  Needs an MI355X: ``pytest -m gpu``.  Tolerance as in
+test_gpu_parity.py (float64 both sides: 1e-9 of the 1e-5 contract)."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+from scipy.sparse import random as sprandom
+
+from conftest import rel_err
+from oracle import cpu_ref
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = 1e-9
+SETTINGS = dict(max_examples=200, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+
+
+@settings(**SETTINGS)
+@given(n_rows=st.integers(1, 900), n_cols=st.integers(1, 80), density=st.floats(0.0, 0.5),
+       k=st.integers(1, 70), frac=st.floats(0.01, 1.0), hot=st.sampled_from([0, -1, 1, 8]),
+       dense_cols=st.integers(0, 3), seed=st.integers(0, 10 ** 6), epochs=st.integers(1, 3))
+def test_fm_fit_random_shapes(n_rows, n_cols, density, k, frac, hot, dense_cols, seed, epochs):
+    import relevance_factorizationmachine_amd as pkg
+    rng = np.random.default_rng(seed)
+
+    def log(m):
+        X = sprandom(m, n_cols, density=density, format="csr", random_state=rng,
+                     data_rvs=lambda s: rng.standard_normal(s)).tolil()
+        for c in range(min(dense_cols, n_cols)):
+            X[:, c] = rng.standard_normal(m)[:, None]
+        X = X.tocsr()
+        X.sort_indices()
+        return {"features": X, "labels": (rng.random(m) < 0.5).astype(np.int64),
+                "pscores": rng.uniform(0.1, 1.0, size=m) ** 0.5}
+
+    train, val = log(n_rows), log(max(1, n_rows // 3))
+    batch = max(1, int(round(frac * n_rows)))
+    kw = dict(n_epochs=epochs, n_factors=k, lr=1e-4, batch_size=batch, seed=seed % 1000)
+    model = pkg.FactorizationMachines(estimator="IPS", n_features=n_cols, **kw)
+    model.hot_min_count = hot
+    tr, va = model.fit(train, val)
+    ref = cpu_ref.fm_fit(train, val, **kw)
+    assert rel_err(model.V(), ref["V"]) < TIGHT
+    assert rel_err(model.w(), ref["w"]) < TIGHT
+    assert abs(model.w0(0) - ref["w0"][0]) < TIGHT * max(1.0, abs(ref["w0"][0]))
+    assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
+    assert rel_err(model.predict(val["features"]),
+                   cpu_ref.fm_predict(val["features"], ref["w0"], ref["w"], ref["V"])) < TIGHT
+
+
+@settings(**SETTINGS)
+@given(n_rows=st.integers(1, 700), nu=st.integers(1, 60), ni=st.integers(1, 60), k=st.integers(1, 140),
+       frac=st.floats(0.01, 1.0), zipf=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_mf_fit_random_shapes(n_rows, nu, ni, k, frac, zipf, seed):
+    import relevance_factorizationmachine_amd as pkg
+    rng = np.random.default_rng(seed)
+
+    def log(m):
+        items = (rng.zipf(1.3, size=m) - 1) % ni if zipf else rng.integers(0, ni, size=m)
+        pairs = np.stack([rng.integers(0, nu, size=m), items], axis=1).astype(np.int64)
+        return {"features": pairs, "labels": (rng.random(m) < 0.5).astype(np.int64),
+                "pscores": rng.uniform(0.1, 1.0, size=m) ** 0.5}
+
+    train, val = log(n_rows), log(max(1, n_rows // 3))
+    batch = max(1, int(round(frac * n_rows)))
+    kw = dict(n_epochs=2, n_factors=k, lr=0.01, batch_size=batch, seed=seed % 1000, n_users=nu, n_items=ni,
+              reg=0.5)
+    model = pkg.LogisticMatrixFactorization(estimator="IPS", **kw)
+    tr, va = model.fit(train, val)
+    ref = cpu_ref.mf_fit(train, val, **kw)
+    for nm in ("P", "Q", "b_u", "b_i"):
+        assert rel_err(getattr(model, nm)(), ref[nm]) < TIGHT, nm
+    assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT

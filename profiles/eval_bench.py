@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """fit() with the per-iteration validation DCG@5 hook: the device
-evaluator (rfm_val_dcg, host fallback only for tie-order dependent iterations) against the
+evaluator (rfm_val_dcg; users whose value depends on the order of tied scores redone on the host) against the
 host callback (predict -> download -> the oracle's restatement of ValEvaluator.evaluate).
 Timing experiment for DESIGN.md; usage: python profiles/eval_bench.py [n_val] [epochs]"""
 import os, sys, time
@@ -43,8 +43,8 @@ for name, rows, alpha in (("all rows, alpha=2 (saturated scores -> ties)", np.ar
         m = pkg.FactorizationMachines(n_epochs=E, evaluator=h, **kw)
         m.device_evaluator = mode
         t0 = time.perf_counter(); m.fit(train, val); dt = time.perf_counter() - t0
-        res[mode] = (dt, h.calls, m.val_metrics)
+        res[mode] = (dt, h.calls, m.val_metrics, getattr(m, "evaluator_host_users", 0))
     same = np.allclose(res[True][2], res[False][2], rtol=1e-12)
     print(f"{name}: frame {len(rows)} rows; fit({E} it) device evaluator {1e3*res[True][0]/E:.2f} ms/it "
-          f"({res[True][1]} host calls), host callback {1e3*res[False][0]/E:.2f} ms/it; "
+          f"({res[True][3]} users redone on the host over all iterations, evaluator called {res[True][1]}x), host callback {1e3*res[False][0]/E:.2f} ms/it; "
           f"speed-up {res[False][0]/res[True][0]:.1f}x; metrics equal: {same}", flush=True)

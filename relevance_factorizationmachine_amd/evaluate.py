@@ -15,9 +15,12 @@ Ranking ties: the device ranks equal scores later-row-first
 (``argsort(kind="stable")[::-1]``).  NumPy's default sort, which the reference
 calls, is not stable and its tie order changes from CPU to CPU, and saturated
 sigmoid scores (exactly 0.0 / 1.0) make ties common.  ``rfm_val_dcg`` therefore
-counts the users whose value depends on the tie order; an iteration with any such
-user is re-evaluated by the evaluator's own ``evaluate`` on the host
-(``EvalLoop``), so ``val_metrics`` is what the host callback would have produced.
+flags the users whose value depends on the tie order; for exactly those users the
+value is recomputed on the host the way the reference does it -- the same
+``ndarray.argsort()[::-1]`` on the same per-user score array, the same formula
+(``utils/metrics.py:53-80``) -- so ``val_metrics`` is what the host callback would
+have produced on this machine, while the unambiguous users (the bulk) never leave
+the device (``EvalLoop``).
 """
 from __future__ import annotations
 
@@ -59,25 +62,59 @@ class DeviceValFrame:
         labels = np.asarray(labels, dtype=np.float64)
         if labels.shape != (n,):
             raise ValueError("labels must match the frame's rows")
+        # host copies in grouped order: the tie-order dependent users are redone from these
+        self.h_order, self.h_seg_ptr = order, seg_ptr
+        self.h_labels = labels[order] if n else np.zeros(0)
+        self.h_pscores = None
         self.rows = rt.upload(order if n else np.zeros(1, np.int32))
         self.seg_ptr = rt.upload(seg_ptr)
-        self.labels = rt.upload(labels[order] if n else np.zeros(1))
+        self.labels = rt.upload(self.h_labels if n else np.zeros(1))
         self.pscores = None
         if pscores is not None:
             pscores = np.asarray(pscores, dtype=np.float64)
             if pscores.shape != (n,):
                 raise ValueError("pscores must match the frame's rows")
-            self.pscores = rt.upload(pscores[order] if n else np.zeros(1))
+            self.h_pscores = pscores[order] if n else np.zeros(0)
+            self.pscores = rt.upload(self.h_pscores if n else np.zeros(1))
         self.scratch = rt.empty((max(3 * self.n_segments, 1),), self.labels.dtype)
 
-    def dcg_into(self, d_scores, out_ptr: int) -> None:
+    def dcg_into(self, d_scores, out_ptr: int, scratch_ptr: Optional[int] = None) -> None:
         """Enqueue the metric of ``d_scores`` (device, frame order): the value and the
-        number of users it is tie-order dependent for land at ``out_ptr`` (2 doubles)."""
+        number of users it is tie-order dependent for land at ``out_ptr`` (2 doubles), the
+        per-user values / counted / order-dependent flags in ``3 * n_segments`` doubles at
+        ``scratch_ptr`` (default: this frame's own scratch)."""
         rt = self.rt
         _lib.check(rt.lib.rfm_val_dcg(
             rt.ctx, d_scores.data_ptr(), self.seg_ptr.data_ptr(), self.rows.data_ptr(),
             self.labels.data_ptr(), None if self.pscores is None else self.pscores.data_ptr(),
-            self.n_segments, self.k, self.scratch.data_ptr(), out_ptr))
+            self.n_segments, self.k, self.scratch.data_ptr() if scratch_ptr is None else scratch_ptr,
+            out_ptr))
+
+    def host_user_value(self, scores: np.ndarray, g: int) -> float:
+        """IPS-DCG@k of user group ``g`` exactly as the reference computes it
+        (utils/evaluate.py:194-204 with utils/metrics.py:53-80), including whatever order
+        NumPy's default sort leaves equal scores in."""
+        lo, hi = int(self.h_seg_ptr[g]), int(self.h_seg_ptr[g + 1])
+        ranked = scores[self.h_order[lo:hi]].argsort()[::-1]
+        y = self.h_labels[lo:hi][ranked]
+        p = np.ones(hi - lo) if self.h_pscores is None else self.h_pscores[lo:hi][ranked]
+        value = 0.0
+        value += y[0] / p[0]
+        tail = y[1:self.k]
+        positions = np.arange(1, tail.shape[0] + 1)
+        value += np.sum(tail / (p[1:self.k] * np.log2(positions + 1)))
+        return float(value)
+
+    def resolve(self, scores: np.ndarray, user_scratch: np.ndarray) -> float:
+        """The metric from the device's per-user results (``user_scratch`` = the
+        ``3 * n_segments`` doubles of one ``dcg_into``) with the order-dependent users
+        recomputed by ``host_user_value``."""
+        n = self.n_segments
+        vals = user_scratch[:n].copy()
+        counted = user_scratch[n: 2 * n] != 0.0
+        for g in np.flatnonzero(user_scratch[2 * n: 3 * n] != 0.0):
+            vals[g] = self.host_user_value(scores, int(g))
+        return float(np.mean(vals[counted]))
 
     def dcg_checked(self, scores):
         """``(value, n_order_dependent_users)`` of host or device scores (frame order)."""
@@ -108,20 +145,24 @@ class EvalLoop:
 
     Per iteration the caller writes the evaluator's scores into ``slot(epoch)`` and
     calls ``done(epoch)``; nothing returns to the host until a chunk of iterations is
-    complete.  Iterations whose value depends on the order of tied scores are then
-    handed, scores and all, to ``evaluator.evaluate`` -- the list ``finish()``
-    returns is what calling the evaluator every iteration would have produced."""
+    complete.  For an iteration with tie-order dependent users, the scores and the
+    per-user results come back and those users are redone the reference's way
+    (``DeviceValFrame.resolve``) -- the list ``finish()`` returns is what calling the
+    evaluator every iteration would have produced on this machine."""
 
     CHUNK_BYTES = 1 << 30
 
     def __init__(self, rt: Runtime, frame: DeviceValFrame, evaluator, estimator: str, n_epochs: int):
         self.rt, self.frame, self.evaluator, self.estimator = rt, frame, evaluator, estimator
         self.n_epochs = n_epochs
-        self.chunk = int(max(1, min(max(n_epochs, 1), self.CHUNK_BYTES // max(8 * frame.n_rows, 8))))
+        per_iter = 8 * (frame.n_rows + 3 * frame.n_segments) + 8
+        self.chunk = int(max(1, min(max(n_epochs, 1), self.CHUNK_BYTES // per_iter)))
         self.scores = rt.empty((self.chunk, max(frame.n_rows, 1)), frame.labels.dtype)
+        self.users = rt.empty((self.chunk, max(3 * frame.n_segments, 1)), frame.labels.dtype)
         self.out = rt.empty((max(n_epochs, 1), 2), frame.labels.dtype)
         self.values: list = []
-        self.host_calls = 0
+        self.host_calls = 0   # iterations that needed host work
+        self.host_users = 0   # users redone on the host, over all iterations
         self._flushed = 0
 
     def slot(self, epoch: int):
@@ -129,7 +170,8 @@ class EvalLoop:
         return self.scores[epoch % self.chunk]
 
     def done(self, epoch: int) -> None:
-        self.frame.dcg_into(self.slot(epoch), self.out.data_ptr() + epoch * 16)
+        self.frame.dcg_into(self.slot(epoch), self.out.data_ptr() + epoch * 16,
+                            self.users[epoch % self.chunk].data_ptr())
         if (epoch + 1) % self.chunk == 0:
             self._flush(epoch + 1)
 
@@ -141,8 +183,10 @@ class EvalLoop:
         for i, epoch in enumerate(range(self._flushed, upto)):
             if o[i, 1] != 0.0:
                 y_scores = self.slot(epoch)[: self.frame.n_rows].cpu().numpy()
-                self.values.append(self.evaluator.evaluate(y_scores=y_scores, estimator=self.estimator))
+                per_user = self.users[epoch % self.chunk].cpu().numpy()
+                self.values.append(self.frame.resolve(y_scores, per_user))
                 self.host_calls += 1
+                self.host_users += int(o[i, 1])
             else:
                 self.values.append(float(o[i, 0]))
         self._flushed = upto

@@ -145,8 +145,8 @@ class FactorizationMachines(PointwiseBaseRecommender):
                 frame = (device_frame(rt, self.evaluator, self.estimator, ev_X.shape[0])
                          if self.device_evaluator else None)
                 if frame is not None:
-                    # ValEvaluator's IPS-DCG@k from the scores in HBM (rfm_val_dcg); only
-                    # iterations whose value hangs on the order of tied scores go to the host
+                    # ValEvaluator's IPS-DCG@k from the scores in HBM (rfm_val_dcg); only the
+                    # users whose value hangs on the order of tied scores are redone on the host
                     if ev_X.shape[1] != self.n_features:
                         raise ValueError(
                             f"X has {ev_X.shape[1]} columns, model has {self.n_features}")
@@ -176,6 +176,7 @@ class FactorizationMachines(PointwiseBaseRecommender):
             if loop is not None:
                 self.val_metrics.extend(loop.finish(self.n_epochs))
                 self.evaluator_host_calls = loop.host_calls
+                self.evaluator_host_users = loop.host_users
             rt.sync()
         finally:
             rt.sync()

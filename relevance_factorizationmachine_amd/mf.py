@@ -170,6 +170,7 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
         if ev_frame is not None:
             self.val_metrics.extend(ev_loop.finish(self.n_epochs))
             self.evaluator_host_calls = ev_loop.host_calls
+            self.evaluator_host_users = ev_loop.host_users
         return tl.cpu().numpy().tolist(), vl.cpu().numpy().tolist()
 
     def _epochs(self, id_stream: BatchIdStream):

@@ -205,9 +205,10 @@ def _unique_pair_frame(val_fm, val_mf):
 @pytest.mark.parametrize("est", ["IPS", "Naive"])
 def test_fm_fit_device_evaluator(ev, est, unique_pairs):
     """fit(evaluator=ValEvaluator-like) equals the host callback iteration by iteration --
-    tie-order dependent iterations (saturated scores, repeated pairs) are the ones sent to
-    the host -- and ends at the value the reference's ValEvaluator gives for the reference's
-    final predictions (fixtures G7 / make_golden_eval.py)."""
+    users whose value hangs on the order of tied scores (saturated scores, repeated pairs) are
+    redone on the host with NumPy's own argsort -- and ends at the value the reference's
+    ValEvaluator gives for the reference's final predictions (fixtures G7 /
+    make_golden_eval.py)."""
     import relevance_factorizationmachine_amd as pkg
     g, g7, gd = load_golden("fm_kuairec_small_k16"), load_golden("val_dcg"), load_golden("val_dcg_distinct")
     sh = synth.SHAPES["kuairec_small"]
@@ -228,7 +229,7 @@ def test_fm_fit_device_evaluator(ev, est, unique_pairs):
     dev = pkg.FactorizationMachines(evaluator=hook, **kw)
     dev.fit(train, val)
     assert len(dev.val_metrics) == E
-    assert hook.calls == dev.evaluator_host_calls <= E
+    assert hook.calls == 0 and dev.evaluator_host_calls <= E  # the evaluator object is never called
     assert dev.val_metrics[-1] == pytest.approx(want, rel=1e-9)
 
     hook2 = _ValEvaluatorLike(frame, {"FM": ev_X})
@@ -296,7 +297,7 @@ def test_mf_fit_device_evaluator(ev):
     hook = _ValEvaluatorLike(frame, {"MF": val["features"]})
     dev = pkg.LogisticMatrixFactorization(evaluator=hook, **kw)
     dev.fit(train, val)
-    assert len(dev.val_metrics) == 3 and hook.calls == dev.evaluator_host_calls
+    assert len(dev.val_metrics) == 3 and hook.calls == 0 and dev.evaluator_host_calls <= 3
     hook2 = _ValEvaluatorLike(frame, {"MF": val["features"]})
     host = pkg.LogisticMatrixFactorization(evaluator=hook2, **kw)
     host.device_evaluator = False

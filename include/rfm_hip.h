@@ -290,8 +290,8 @@ int32_t rfm_mf_sgd_hogwild(rfm_ctx* ctx, const int32_t* d_users, const int32_t* 
  * d_out[1] = number of counted groups whose value depends on that order (a tie
  * reaching into the first k ranks between rows of different label or propensity,
  * or a NaN score, which is never ranked here).  With d_out[1] == 0 the value is the
- * reference's; otherwise the caller decides (the Python mirror re-evaluates such an
- * iteration with the evaluator's own host code).  d_pscores == NULL means all ones
+ * reference's; otherwise the caller decides (the Python mirror redoes exactly those
+ * groups on the host with NumPy's own sort, from the per-group flags below).  d_pscores == NULL means all ones
  * (the Naive estimator's ones_pscore column; also calc_dcg_at_k of
  * utils/metrics.py:83-107).  d_user_scratch: 3*n_segments doubles; after the call
  * [0, n) holds the per-group values, [n, 2n) 1.0 / 0.0 for counted / left out and

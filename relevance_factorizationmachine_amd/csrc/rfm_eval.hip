@@ -12,9 +12,8 @@
 // where it leaves equal scores depends on the host CPU, so the kernel also reports
 // the users for whom that order can change the value (a tie that reaches into the
 // first k ranks between rows of different label or propensity -- saturated sigmoid
-// scores make these common -- or a NaN score); the caller falls back to the host
-// evaluator for an iteration with any such user, which keeps fit() identical to
-// the reference's.
+// scores make these common -- or a NaN score); the caller redoes exactly those users
+// on the host with NumPy's own sort, which keeps fit() identical to the reference's.
 #include "rfm_common.h"
 
 using namespace rfm;

@@ -46,49 +46,30 @@ def group_by_user(users: np.ndarray):
     return order, seg_ptr
 
 
-class DeviceValFrame:
-    """A validation frame resident in HBM in grouped order."""
+class ValFrame:
+    """A validation frame grouped by user, on the host: what the order-dependent users are
+    redone from (and all that is needed to restate ``ValEvaluator.evaluate`` without a GPU)."""
 
-    def __init__(self, rt: Runtime, users, labels, pscores: Optional[np.ndarray], k: int):
+    def __init__(self, users, labels, pscores: Optional[np.ndarray], k: int):
         users = np.asarray(users)
         if users.ndim != 1:
             raise ValueError("users must be a 1-D array")
         n = users.shape[0]
         if k < 1:
             raise ValueError("k (ranking positions) must be >= 1")
-        self.rt, self.k, self.n_rows = rt, int(k), int(n)
-        order, seg_ptr = group_by_user(users)
-        self.n_segments = int(seg_ptr.shape[0] - 1)
+        self.k, self.n_rows = int(k), int(n)
+        self.h_order, self.h_seg_ptr = group_by_user(users)
+        self.n_segments = int(self.h_seg_ptr.shape[0] - 1)
         labels = np.asarray(labels, dtype=np.float64)
         if labels.shape != (n,):
             raise ValueError("labels must match the frame's rows")
-        # host copies in grouped order: the tie-order dependent users are redone from these
-        self.h_order, self.h_seg_ptr = order, seg_ptr
-        self.h_labels = labels[order] if n else np.zeros(0)
+        self.h_labels = labels[self.h_order] if n else np.zeros(0)
         self.h_pscores = None
-        self.rows = rt.upload(order if n else np.zeros(1, np.int32))
-        self.seg_ptr = rt.upload(seg_ptr)
-        self.labels = rt.upload(self.h_labels if n else np.zeros(1))
-        self.pscores = None
         if pscores is not None:
             pscores = np.asarray(pscores, dtype=np.float64)
             if pscores.shape != (n,):
                 raise ValueError("pscores must match the frame's rows")
-            self.h_pscores = pscores[order] if n else np.zeros(0)
-            self.pscores = rt.upload(self.h_pscores if n else np.zeros(1))
-        self.scratch = rt.empty((max(3 * self.n_segments, 1),), self.labels.dtype)
-
-    def dcg_into(self, d_scores, out_ptr: int, scratch_ptr: Optional[int] = None) -> None:
-        """Enqueue the metric of ``d_scores`` (device, frame order): the value and the
-        number of users it is tie-order dependent for land at ``out_ptr`` (2 doubles), the
-        per-user values / counted / order-dependent flags in ``3 * n_segments`` doubles at
-        ``scratch_ptr`` (default: this frame's own scratch)."""
-        rt = self.rt
-        _lib.check(rt.lib.rfm_val_dcg(
-            rt.ctx, d_scores.data_ptr(), self.seg_ptr.data_ptr(), self.rows.data_ptr(),
-            self.labels.data_ptr(), None if self.pscores is None else self.pscores.data_ptr(),
-            self.n_segments, self.k, self.scratch.data_ptr() if scratch_ptr is None else scratch_ptr,
-            out_ptr))
+            self.h_pscores = pscores[self.h_order] if n else np.zeros(0)
 
     def host_user_value(self, scores: np.ndarray, g: int) -> float:
         """IPS-DCG@k of user group ``g`` exactly as the reference computes it
@@ -107,7 +88,7 @@ class DeviceValFrame:
 
     def resolve(self, scores: np.ndarray, user_scratch: np.ndarray) -> float:
         """The metric from the device's per-user results (``user_scratch`` = the
-        ``3 * n_segments`` doubles of one ``dcg_into``) with the order-dependent users
+        ``3 * n_segments`` doubles of one ``rfm_val_dcg``) with the order-dependent users
         recomputed by ``host_user_value``."""
         n = self.n_segments
         vals = user_scratch[:n].copy()
@@ -115,6 +96,34 @@ class DeviceValFrame:
         for g in np.flatnonzero(user_scratch[2 * n: 3 * n] != 0.0):
             vals[g] = self.host_user_value(scores, int(g))
         return float(np.mean(vals[counted]))
+
+
+class DeviceValFrame(ValFrame):
+    """The grouped frame resident in HBM."""
+
+    def __init__(self, rt: Runtime, users, labels, pscores: Optional[np.ndarray], k: int):
+        super().__init__(users, labels, pscores, k)
+        self.rt = rt
+        n = self.n_rows
+        self.rows = rt.upload(self.h_order if n else np.zeros(1, np.int32))
+        self.seg_ptr = rt.upload(self.h_seg_ptr)
+        self.labels = rt.upload(self.h_labels if n else np.zeros(1))
+        self.pscores = None
+        if self.h_pscores is not None:
+            self.pscores = rt.upload(self.h_pscores if n else np.zeros(1))
+        self.scratch = rt.empty((max(3 * self.n_segments, 1),), self.labels.dtype)
+
+    def dcg_into(self, d_scores, out_ptr: int, scratch_ptr: Optional[int] = None) -> None:
+        """Enqueue the metric of ``d_scores`` (device, frame order): the value and the
+        number of users it is tie-order dependent for land at ``out_ptr`` (2 doubles), the
+        per-user values / counted / order-dependent flags in ``3 * n_segments`` doubles at
+        ``scratch_ptr`` (default: this frame's own scratch)."""
+        rt = self.rt
+        _lib.check(rt.lib.rfm_val_dcg(
+            rt.ctx, d_scores.data_ptr(), self.seg_ptr.data_ptr(), self.rows.data_ptr(),
+            self.labels.data_ptr(), None if self.pscores is None else self.pscores.data_ptr(),
+            self.n_segments, self.k, self.scratch.data_ptr() if scratch_ptr is None else scratch_ptr,
+            out_ptr))
 
     def dcg_checked(self, scores):
         """``(value, n_order_dependent_users)`` of host or device scores (frame order)."""

@@ -171,3 +171,45 @@ def test_evaluator_grouping_and_recognition():
     Val.metric_name = "Recall"
     assert evaluate.recognise(Val(), "IPS") is None
     assert evaluate.recognise(object(), "IPS") is None
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/utils"), reason="the reference tree is only in the build container")
+def test_host_tie_resolution_equals_reference_val_evaluator():
+    """The host half of the device evaluator against the reference's own ValEvaluator
+    (imported from /root/reference, build container only): with 10 % of the scores tied at
+    1.0 -- the case whose ranking NumPy's unstable sort decides -- redoing users with
+    ``ValFrame.host_user_value`` gives the reference's value exactly, the evaluator is
+    recognised, and its frame is not touched."""
+    import sys
+
+    import pandas as pd
+
+    from relevance_factorizationmachine_amd import evaluate
+
+    saved = {k: v for k, v in sys.modules.items() if k == "utils" or k.startswith("utils.")}
+    for k in saved:
+        del sys.modules[k]
+    sys.path.insert(0, "/root/reference")
+    try:
+        from utils.evaluate import ValEvaluator
+    finally:
+        sys.path.remove("/root/reference")
+        for k in [m for m in sys.modules if m == "utils" or m.startswith("utils.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "val_dcg.npz"))
+    cols = {c: g[c] for c in ("user", "item", "label", "pscore", "ones_pscore")}
+    ev = ValEvaluator(interaction_df=pd.DataFrame(cols), features={}, k=5, metric_name="DCG")
+    before = ev.interaction_df.copy()
+    for est, pcol in (("IPS", "pscore"), ("Naive", "ones_pscore")):
+        users, labels, pscores, k = evaluate.recognise(ev, est)
+        np.testing.assert_array_equal(pscores, cols[pcol])
+        frame = evaluate.ValFrame(users, labels, pscores, k)
+        n = frame.n_segments
+        # as if the device had flagged every counted user as order dependent
+        counted = np.array([frame.h_labels[frame.h_seg_ptr[u]:frame.h_seg_ptr[u + 1]].sum() != 0 for u in range(n)])
+        scratch = np.concatenate([np.zeros(n), counted.astype(np.float64), counted.astype(np.float64)])
+        got = frame.resolve(g["scores"], scratch)
+        assert got == ev.evaluate(y_scores=g["scores"], estimator=est) == float(g[f"val_dcg_{est}"])
+    pd.testing.assert_frame_equal(ev.interaction_df.drop(columns=["y_score"]), before)

@@ -409,7 +409,10 @@ __device__ __forceinline__ void mf_slot_fetch(const MfExArgs& a, const MfSeqLds&
   s.has = has;
   s.got_user = PF && has && s.e.gap > ahead;
   s.got_item = PF && has && s.e.cslot == -1;
-  if (PF) {
+  // a wavefront none of whose lane groups has an example at that level issues nothing
+  // (the condition is uniform in the wavefront, so the loads of an active one stay
+  // unconditional and together)
+  if (PF && __ballot(has) != 0ull) {
     const int k = a.k;
     const int32_t u = s.got_user ? s.e.u : 0;
     const int32_t it = s.got_item ? s.e.i : 0;

@@ -86,15 +86,37 @@ class ValFrame:
         value += np.sum(tail / (p[1:self.k] * np.log2(positions + 1)))
         return float(value)
 
+    def host_user_values(self, scores: np.ndarray, groups: np.ndarray) -> np.ndarray:
+        """``host_user_value`` of many groups at once: groups of equal length are stacked and
+        ranked by one ``argsort(axis=1)`` -- NumPy runs the same 1-D sort on every row, so each
+        row gets the order (ties included) its own ``argsort()`` call would give."""
+        out = np.empty(groups.shape[0], dtype=np.float64)
+        lo = self.h_seg_ptr[groups].astype(np.int64)
+        lens = self.h_seg_ptr[groups + 1].astype(np.int64) - lo
+        for length in np.unique(lens):
+            sel = np.flatnonzero(lens == length)
+            idx = lo[sel][:, None] + np.arange(length)[None, :]
+            ranked = np.argsort(scores[self.h_order[idx]], axis=1)[:, ::-1]
+            y = np.take_along_axis(self.h_labels[idx], ranked, axis=1)
+            p = (np.ones_like(y) if self.h_pscores is None
+                 else np.take_along_axis(self.h_pscores[idx], ranked, axis=1))
+            value = 0.0 + y[:, 0] / p[:, 0]
+            tail = y[:, 1:self.k]
+            positions = np.arange(1, tail.shape[1] + 1)
+            value = value + np.sum(tail / (p[:, 1:self.k] * np.log2(positions + 1)[None, :]), axis=1)
+            out[sel] = value
+        return out
+
     def resolve(self, scores: np.ndarray, user_scratch: np.ndarray) -> float:
         """The metric from the device's per-user results (``user_scratch`` = the
         ``3 * n_segments`` doubles of one ``rfm_val_dcg``) with the order-dependent users
-        recomputed by ``host_user_value``."""
+        recomputed the reference's way on the host."""
         n = self.n_segments
         vals = user_scratch[:n].copy()
         counted = user_scratch[n: 2 * n] != 0.0
-        for g in np.flatnonzero(user_scratch[2 * n: 3 * n] != 0.0):
-            vals[g] = self.host_user_value(scores, int(g))
+        redo = np.flatnonzero(user_scratch[2 * n: 3 * n] != 0.0)
+        if redo.size:
+            vals[redo] = self.host_user_values(scores, redo)
         return float(np.mean(vals[counted]))
 
 

@@ -41,10 +41,13 @@
 // reproducible); hot-class sums inside one workgroup are LDS atomics, so their
 // last bits may vary from run to run (hot_min_count < 0 turns the class off).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <memory>
 #include <numeric>
+#include <string>
+#include <thread>
 
 #include "rfm_common.h"
 #include "rfm_fm_kernels.hpp"
@@ -413,23 +416,76 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
     const size_t nf = static_cast<size_t>(n_features);
     const size_t nr = static_cast<size_t>(n_rows);
 
+    const bool timing = env_int("RFM_PLAN_TIMING", 0) != 0;
+    auto t_prev = std::chrono::steady_clock::now();
+    const auto lap = [&](const char* what) {
+      if (!timing) return;
+      const auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "[plan] %s: %.1f ms\n", what,
+              std::chrono::duration<double, std::milli>(now - t_prev).count());
+      t_prev = now;
+    };
+    // Host threads of the two passes over the CSR: rows are cut into contiguous ranges,
+    // every thread counts its range's entries per column, and the prefix of those counts
+    // over the threads gives each thread its own first slot in every column (row order
+    // inside a column is kept).  The per-thread tables are n_features ints each.
+    const int hw = int(std::thread::hardware_concurrency());
+    int n_thr = std::max(1, std::min({env_int("RFM_PLAN_THREADS", 16), hw > 0 ? hw : 1,
+                                      int(std::max<int64_t>(1, (int64_t(64) << 20) / n_features)),
+                                      int(std::max<int64_t>(1, nnz / 200000))}));
+    const auto row_lo = [&](int t) { return n_rows * t / n_thr; };
+    std::vector<std::string> thr_err(static_cast<size_t>(n_thr));
+    const auto run_threads = [&](auto&& body) {
+      if (n_thr == 1) {
+        body(0);
+      } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_thr; ++t) pool.emplace_back([&, t] { body(t); });
+        for (auto& th : pool) th.join();
+      }
+      for (const std::string& e : thr_err)
+        if (!e.empty()) fail(RFM_ERR_BAD_ARG, "%s", e.c_str());
+    };
+    const auto thread_fail = [&](int t, const char* fmt, long long a, long long b) {
+      char buf[256];
+      snprintf(buf, sizeof(buf), fmt, a, b);
+      if (thr_err[size_t(t)].empty()) thr_err[size_t(t)] = buf;
+    };
+
     // column lengths; a row must not name a column twice (SciPy sums such duplicates
     // before squaring -- the caller canonicalises, as the Python mirror does)
-    std::vector<int64_t> len(nf, 0);
-    {
+    std::vector<std::vector<int32_t>> cnt_tc(static_cast<size_t>(n_thr));  // [thread][column]
+    run_threads([&](int t) {
+      std::vector<int32_t>& cnt = cnt_tc[size_t(t)];
+      cnt.assign(nf, 0);
       std::vector<int64_t> seen_in_row(nf, -1);
-      for (int64_t r = 0; r < n_rows; ++r)
-        for (int64_t p = h_indptr[r]; p < h_indptr[r + 1]; ++p) {
-          RFM_REQUIRE(p >= 0 && p < nnz, "indptr out of range at row %lld", (long long)r);
-          const int32_t c = h_indices[p];
-          RFM_REQUIRE(c >= 0 && c < n_features, "column index %d out of range", c);
-          RFM_REQUIRE(seen_in_row[size_t(c)] != r,
-                      "row %lld names column %d twice: sum duplicate entries first", (long long)r,
-                      c);
-          seen_in_row[size_t(c)] = r;
-          len[size_t(c)]++;
+      for (int64_t r = row_lo(t); r < row_lo(t + 1); ++r) {
+        const int64_t b = h_indptr[r], e = h_indptr[r + 1];
+        if (b < 0 || e < b || e > nnz) {
+          thread_fail(t, "indptr not monotone / out of range at row %lld (nnz %lld)", (long long)r,
+                      (long long)nnz);
+          return;
         }
-    }
+        for (int64_t p = b; p < e; ++p) {
+          const int32_t c = h_indices[p];
+          if (c < 0 || c >= n_features) {
+            thread_fail(t, "column index %lld out of range (row %lld)", (long long)c, (long long)r);
+            return;
+          }
+          if (seen_in_row[size_t(c)] == r) {
+            thread_fail(t, "row %lld names column %lld twice: sum duplicate entries first",
+                        (long long)r, (long long)c);
+            return;
+          }
+          seen_in_row[size_t(c)] = r;
+          cnt[size_t(c)]++;
+        }
+      }
+    });
+    std::vector<int64_t> len(nf, 0);
+    for (int t = 0; t < n_thr; ++t)
+      for (size_t c = 0; c < nf; ++c) len[c] += cnt_tc[size_t(t)][c];
+    lap("count pass");
     // hot class: expected entries per batch >= hot_min, most frequent first, LDS budget
     std::vector<int32_t> hot_cols;
     std::vector<int32_t> hot_rank(nf, -1);
@@ -452,29 +508,46 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
     for (size_t c = 0; c < nf; ++c) cptr[c + 1] = cptr[c] + (hot_rank[c] >= 0 ? 0 : len[c]);
     const int64_t n_slots = cptr[nf];
     const size_t ns = static_cast<size_t>(n_slots);
-    std::vector<Entry> ent(nz + 1, Entry{0, 0, 0.0});  // +1: clamp target of empty logs
-    std::vector<RowRec> rows(nr);
-    std::vector<SlotRec> slots(ns + 256, SlotRec{0.0, 0, 0});  // padded by one window
+    lap("classes");
+    // staging buffers, left uninitialised: the threads of the fill pass write every element
+    // (and so fault the pages in, in parallel); only the paddings are set here
+    std::unique_ptr<Entry[]> ent(new Entry[nz + 1]);  // +1: clamp target of empty logs
+    ent[nz] = Entry{0, 0, 0.0};
+    std::unique_ptr<RowRec[]> rows(new RowRec[nr]);
+    std::unique_ptr<SlotRec[]> slots(new SlotRec[ns + 256]);  // padded by one window
+    for (size_t i = ns; i < ns + 256; ++i) slots[i] = SlotRec{0.0, 0, 0};
     {
-      std::vector<int64_t> cursor(cptr.begin(), cptr.end() - 1);
-      for (int64_t r = 0; r < n_rows; ++r) {
-        const int64_t b = h_indptr[r], e = h_indptr[r + 1];
-        RFM_REQUIRE(e >= b && e <= nnz, "indptr not monotone at row %lld", (long long)r);
-        rows[size_t(r)] = RowRec{b, e - b, h_y[r], h_pscore[r]};
-        for (int64_t p = b; p < e; ++p) {
-          const int32_t c = h_indices[p];
-          Entry en{c, 0, h_values[p]};
-          if (hot_rank[size_t(c)] >= 0) {
-            en.slot = -1 - hot_rank[size_t(c)];
-          } else {
-            const int64_t s = cursor[size_t(c)]++;
-            en.slot = int32_t(s);
-            slots[size_t(s)] = SlotRec{h_values[p], c, 0};
-          }
-          ent[size_t(p)] = en;
+      // thread t's first slot of column c: the column's base plus what earlier threads hold
+      std::vector<std::vector<int64_t>> cur_tc(static_cast<size_t>(n_thr));
+      for (int t = 0; t < n_thr; ++t) cur_tc[size_t(t)].resize(nf);
+      for (size_t c = 0; c < nf; ++c) {
+        int64_t at = cptr[c];
+        for (int t = 0; t < n_thr; ++t) {
+          cur_tc[size_t(t)][c] = at;
+          at += cnt_tc[size_t(t)][c];
         }
       }
+      run_threads([&](int t) {
+        std::vector<int64_t>& cursor = cur_tc[size_t(t)];
+        for (int64_t r = row_lo(t); r < row_lo(t + 1); ++r) {
+          const int64_t b = h_indptr[r], e = h_indptr[r + 1];
+          rows[size_t(r)] = RowRec{b, e - b, h_y[r], h_pscore[r]};
+          for (int64_t p = b; p < e; ++p) {
+            const int32_t c = h_indices[p];
+            Entry en{c, 0, h_values[p]};
+            if (hot_rank[size_t(c)] >= 0) {
+              en.slot = -1 - hot_rank[size_t(c)];
+            } else {
+              const int64_t sl = cursor[size_t(c)]++;
+              en.slot = int32_t(sl);
+              slots[size_t(sl)] = SlotRec{h_values[p], c, 0};
+            }
+            ent[size_t(p)] = en;
+          }
+        }
+      });
     }
+    lap("allocate + fill pass");
     // fixed slot windows (one per lane group of fm_consume_kernel) and the columns
     // that cross a window border, with the carry rows they collect in window order
     const Shape shp = shape_for(n_factors);
@@ -508,6 +581,7 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
     std::vector<CrossCol> cross(cross_short);
     cross.insert(cross.end(), cross_long.begin(), cross_long.end());
 
+    lap("windows + crossing lists");
     RFM_HIP_CHECK(hipSetDevice(ctx->device));
     auto plan = std::make_unique<rfm_fm_plan>();
     plan->device = ctx->device;
@@ -521,9 +595,9 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
     plan->n_cross_short = int32_t(cross_short.size());
     plan->n_cross_long = int32_t(cross_long.size());
     plan->n_hot = int32_t(hot_cols.size());
-    upload(plan->ent, ent.data(), (nz + 1) * sizeof(Entry), ctx->stream);
-    upload(plan->rows, rows.data(), nr * sizeof(RowRec), ctx->stream);
-    upload(plan->slots, slots.data(), slots.size() * sizeof(SlotRec), ctx->stream);
+    upload(plan->ent, ent.get(), (nz + 1) * sizeof(Entry), ctx->stream);
+    upload(plan->rows, rows.get(), nr * sizeof(RowRec), ctx->stream);
+    upload(plan->slots, slots.get(), (ns + 256) * sizeof(SlotRec), ctx->stream);
     upload(plan->win, win.data(), win.size() * sizeof(WinInfo), ctx->stream);
     upload(plan->cross, cross.data(), cross.size() * sizeof(CrossCol), ctx->stream);
     upload(plan->carry_idx, carry_idx.data(), carry_idx.size() * 4, ctx->stream);
@@ -541,6 +615,15 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
     plan->err.alloc(size_t(max_batch) * 8);
     // host vectors die at scope exit: wait for the copies
     RFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    lap("device allocations + uploads");
+    // giving 270 MB of touched pages back to the kernel takes tens of milliseconds: let a
+    // detached thread do it while the caller goes on
+    std::thread([e = std::move(ent), r = std::move(rows), sl = std::move(slots)]() mutable {
+      e.reset();
+      r.reset();
+      sl.reset();
+    }).detach();
+    lap("hand staging to the freeing thread");
     *out = plan.release();
   });
 }

@@ -71,3 +71,32 @@ def test_mf_fit_random_shapes(n_rows, nu, ni, k, frac, zipf, seed):
     for nm in ("P", "Q", "b_u", "b_i"):
         assert rel_err(getattr(model, nm)(), ref[nm]) < TIGHT, nm
     assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
+
+
+@settings(**SETTINGS)
+@given(n=st.integers(1, 3000), n_users=st.integers(1, 60), k=st.integers(1, 12), levels=st.integers(1, 40),
+       p_pos=st.floats(0.0, 1.0), binary_p=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_device_evaluator_with_ties_equals_numpy_ranking(n, n_users, k, levels, p_pos, binary_p, seed):
+    """Scores quantised to a few levels (ties everywhere, as saturated sigmoids give): the device
+    value with its flagged users redone on the host must equal the reference's computation --
+    per-user ``argsort()[::-1]`` with whatever order NumPy leaves ties in -- so a tie that can
+    change the value and is NOT flagged shows up here."""
+    from relevance_factorizationmachine_amd import evaluate, runtime
+    rt = runtime.Runtime.get()
+    rng = np.random.default_rng(seed)
+    users = rng.integers(0, n_users, size=n)
+    labels = (rng.random(n) < p_pos).astype(np.int64)
+    pscore = rng.choice([0.25, 1.0], size=n) if binary_p else rng.uniform(0.1, 1.0, size=n)
+    scores = rng.integers(0, levels, size=n) / float(levels)
+    frame = {"user": users, "label": labels, "pscore": pscore, "ones_pscore": np.ones(n)}
+    fr = evaluate.DeviceValFrame(rt, users, labels, pscore, k)
+    d = rt.upload(scores)
+    out = rt.empty((2,), d.dtype)
+    fr.dcg_into(d, out.data_ptr())
+    rt.sync()
+    got = fr.resolve(scores, fr.scratch.cpu().numpy())
+    if labels.sum() == 0:
+        assert np.isnan(got)
+        return
+    want = cpu_ref.val_dcg(frame, scores, "IPS", k=k)
+    assert got == pytest.approx(want, rel=1e-12)

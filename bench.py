@@ -7,20 +7,43 @@ synthetic log (BASELINE.json config 3), one process per GPU.
 A *step* is one mini-batch pass of the hot path over rows already resident in
 HBM: gather by row id -> forward -> IPS residual -> batch-sum gradients -> SGD
 update of w0, w, V (src/fm.py:72-88 of the reference).  The row-id lists of the
-K+W batches (the reference's resample(..., random_state=epoch)) are produced by
-the exact host sampler before the timed region and uploaded: they are inputs.
-For N > 1 the global batch of N*B rows is sharded over the ranks, gradients
-are all-reduced over RCCL and every rank applies the same update (weak scaling:
-B rows per GPU).  Rank 0 prints ONE JSON line.
+batches (the reference's resample(..., random_state=epoch)) are produced by the
+exact host sampler before the timed region and uploaded: they are inputs.
+For N > 1 the global batch of N*B rows is sharded over the ranks, gradients are
+exchanged over RCCL and every rank applies the same update (weak scaling: B rows
+per GPU).  Rank 0 prints ONE JSON line.
+
+What the line carries besides the contract's fields:
+ * the timed region (exactly K steps between barrier + synchronize) is repeated
+   --reps times; ``value`` / ``ms_per_step`` are the MEDIAN region, all regions
+   are listed in ``extra.rep_ms_per_step``;
+ * ``roofline``: the dominant kernel priced with SURVEY 8d's ALGORITHMIC bytes,
+   the same model applied to the whole step (``whole_step_frac``; above 1 at
+   this config because V is cache-resident -- then ``bound`` says
+   "latency/L2", not "hbm"), a PHYSICAL model (``compulsory_hbm_bytes``: what
+   must cross HBM from cold caches) and the COUNTER view (``traffic``: HBM bytes
+   per launch from rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this very command,
+   collected by child processes before this process touches the GPU);
+ * ``extra.fit_wall``: variant (A), ``FactorizationMachines.fit`` exactly as the
+   reference runs it (second batch forward + per-iteration validation forward,
+   sampler, uploads and plan build included) at B = 2 000 and 65 536, and
+   ``cpu_baseline.fit_wall`` for the oracle's reference-structured fit.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import csv
+import glob
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
+from collections import defaultdict
 
 import numpy as np
 
@@ -31,6 +54,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+STEP_KERNELS = ["fm_forward_kernel", "fm_consume_kernel", "fm_finalize_kernel"]
 
 
 def algorithmic_bytes(z: float, k: int, s: int = 8):
@@ -41,7 +65,146 @@ def algorithmic_bytes(z: float, k: int, s: int = 8):
     return fwd, upd
 
 
-def cpu_baseline(train, ids, k, lr, seed, budget_s=15.0):
+def kernels_sha() -> str:
+    """Identity of the kernel sources a traffic figure belongs to."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "relevance_factorizationmachine_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def git_head() -> str | None:
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True,
+                              text=True, timeout=10).stdout.strip() or None
+    except Exception:  # noqa: BLE001
+        return None
+
+
+# ---------------------------------------------------------------------------
+# HBM traffic from the PMC counters, measured by this run
+# ---------------------------------------------------------------------------
+def _per_kernel_counter(dirpath: str, counter: str):
+    acc = defaultdict(lambda: [0.0, 0])
+    for path in glob.glob(os.path.join(dirpath, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") != counter:
+                    continue
+                name = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].replace("rfm::", "")
+                acc[name][0] += float(row["Counter_Value"])
+                acc[name][1] += 1
+    return {k: v[0] / v[1] for k, v in acc.items() if v[1]}
+
+
+def collect_traffic(args) -> dict:
+    """rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes: the TCC slots do
+    not hold both; --kernel-trace only, as MI355X_MICROARCH.md's rocprofv3 section says) of
+    this same bench command in child processes.  Called BEFORE this process initialises the
+    GPU.  FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports half the bytes of
+    wide coalesced reads, so the read side is doubled (same guide, HBM section)."""
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {"error": "rocprofv3 not found"}
+    keep = os.path.join(ROOT, "gpurun_out", "bench_pmc")
+    try:
+        os.makedirs(keep, exist_ok=True)
+    except OSError:
+        keep = None
+    work = tempfile.mkdtemp(prefix="rfm_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(args.steps), "--warmup",
+             str(args.warmup), "--batch-size", str(args.batch_size), "--workload", args.workload,
+             "--n-train", str(args.n_train), "--reps", "1", "--pmc-child"]
+    per = {}
+    t0 = time.perf_counter()
+    for tag, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        out = os.path.join(work, tag)
+        cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--"] + child
+        try:
+            proc = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True,
+                                  timeout=args.pmc_timeout)
+        except subprocess.TimeoutExpired:
+            return {"error": f"rocprofv3 --pmc {counter} pass timed out after {args.pmc_timeout} s"}
+        if proc.returncode != 0:
+            return {"error": f"rocprofv3 --pmc {counter} pass failed (rc {proc.returncode}): "
+                             + (proc.stderr or proc.stdout)[-300:]}
+        per[counter] = _per_kernel_counter(out, counter)
+    shutil.rmtree(work, ignore_errors=True)
+    kernels = {}
+    for name in sorted(set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"])):
+        f = per["FETCH_SIZE"].get(name, 0.0) * 1024
+        w = per["WRITE_SIZE"].get(name, 0.0) * 1024
+        kernels[name] = {"fetch_bytes_raw": f, "fetch_bytes_x2": 2 * f, "write_bytes": w, "hbm_bytes": 2 * f + w}
+    if not any(k in kernels for k in STEP_KERNELS):
+        return {"error": "the PMC passes saw none of the step's kernels"}
+    res = {"kernels": kernels, "seconds": time.perf_counter() - t0, "kernels_sha": kernels_sha(),
+           "commit": git_head(), "batch": args.batch_size, "workload": args.workload,
+           "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace, one pass each, of "
+                  "`bench.py --pmc-child` with this run's steps/warmup/batch; average per launch; "
+                  "hbm_bytes = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 (gfx950 FETCH_SIZE correction)"}
+    if keep:
+        try:
+            json.dump(res, open(os.path.join(keep, "pmc_summary.json"), "w"), indent=1)
+        except OSError:
+            pass
+    return res
+
+
+def committed_traffic(batch: int, workload: str) -> dict | None:
+    """Fallback when this run cannot profile itself: the newest committed
+    profiles/r*/pmc_summary.json that names its commit and was taken from THESE kernel
+    sources (kernels_sha); anything older than the kernels is refused."""
+    sha = kernels_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:  # noqa: BLE001
+            continue
+        if d.get("kernels_sha") == sha and d.get("batch") == batch and d.get("workload") == workload \
+                and "kernels" in d:
+            d["path"] = os.path.relpath(path, ROOT)
+            return d
+    return None
+
+
+# ---------------------------------------------------------------------------
+# physical model: bytes that must cross HBM from cold caches, per step
+# ---------------------------------------------------------------------------
+def compulsory_bytes(X, rows: np.ndarray, k: int, hot_cols: np.ndarray, n_slabs: int) -> dict:
+    """Per launch, from cold caches: every byte of the batch's records, ids, Q / residual,
+    slot marks and hot-sum slabs once in each direction it has to travel, and every DISTINCT
+    touched parameter row (V row + w entry) read once by the forward and read + written once
+    by the update.  No cross-row reuse is assumed for the records; parameters count once."""
+    B = int(rows.shape[0])
+    sub = X[rows]
+    cols = sub.indices
+    nnz = int(cols.shape[0])
+    distinct = int(np.unique(cols).shape[0])
+    is_hot = np.zeros(X.shape[1], dtype=bool)
+    is_hot[hot_cols] = True
+    sparse_entries = int(np.count_nonzero(~is_hot[cols]))
+    H = int(hot_cols.shape[0])
+    param_row = (k + 1) * 8
+    slab = n_slabs * H * (k + 2) * 8
+    fwd = (B * 4 + B * 32 + nnz * 16          # ids, row records, entry records
+           + distinct * param_row              # touched rows of V, entries of w
+           + B * k * 8 + B * 8                 # Q, residual out
+           + sparse_entries * 4                # slot marks
+           + slab + n_slabs * 8)               # hot sums, residual partials
+    cons = (sparse_entries * (4 + 4 + 16)     # marks read + reset, slot records
+            + sparse_entries * (k * 8 + 8)     # Q rows, residuals of the marked slots
+            + slab                             # slabs read back
+            + 2 * (distinct - H) * param_row)  # sparse-class rows read + written
+    fin = 2 * H * param_row + H * 4 * (k + 2) * 8 * 2  # hot rows read + written, part rows
+    return {"forward": fwd, "consume": cons, "finalize": fin, "step": fwd + cons + fin,
+            "distinct_columns": distinct, "sparse_entries": sparse_entries, "hot_columns": H}
+
+
+def cpu_baseline(train, ids, k, lr, seed, budget_s=10.0):
     """The oracle's reference-structured step (same SciPy op sequence as
     src/fm.py:80-88,135-187, per-factor loop included) on the host cores."""
     from oracle import cpu_ref
@@ -58,11 +221,26 @@ def cpu_baseline(train, ids, k, lr, seed, budget_s=15.0):
     return done * len(ids[0]) / dt, done, dt
 
 
+def cpu_fit_wall(train, val, k, lr, seed, batch, n_epochs):
+    """Variant (A) on the host: the oracle's fit() in the reference's structure
+    (src/fm.py:71-102: resample, step, train-loss forward, validation forward)."""
+    from oracle import cpu_ref
+
+    t0 = time.perf_counter()
+    cpu_ref.fm_fit(train, val, n_epochs=n_epochs, n_factors=k, lr=lr, batch_size=batch, seed=seed,
+                   form="refstruct")
+    dt = time.perf_counter() - t0
+    return {"batch_size": batch, "iterations": n_epochs, "ms_per_iteration": 1e3 * dt / n_epochs,
+            "value": n_epochs * batch / dt, "unit": "examples/s"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=5,
+                    help="repetitions of the K-step timed region; the median is reported")
     ap.add_argument("--batch-size", type=int, default=65536, help="rows per GPU per step")
     ap.add_argument("--n-train", type=int, default=0, help="rows of the synthetic log (0 = config)")
     ap.add_argument("--workload", default="kuairec_big")
@@ -72,11 +250,31 @@ def main() -> None:
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --batch-size is the GLOBAL batch, split over the GPUs "
                          "(default: weak scaling, --batch-size rows per GPU)")
+    ap.add_argument("--exchange", default="rows", choices=["rows", "dense"],
+                    help="multi-GPU gradient exchange: touched rows only (default) or the dense "
+                         "[G_V|g_w|g_w0] all-reduce the north star names as the baseline")
     ap.add_argument("--no-direct-rccl", action="store_true",
-                    help="multi-GPU: exchange through torch.distributed instead of the C ABI's RCCL binding")
+                    help="multi-GPU dense exchange through torch.distributed instead of the C ABI's RCCL binding")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes")
+    ap.add_argument("--pmc-timeout", type=int, default=240)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        args.no_cpu_baseline = args.no_extra = args.no_pmc = True
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    # the counter passes run this command again under rocprofv3 in child processes; they
+    # come first because a process that has initialised the GPU must not start them
+    traffic_info = None
+    if world == 1 and not args.no_pmc:
+        traffic_info = collect_traffic(args)
 
     import torch
     import torch.distributed as dist
@@ -86,11 +284,6 @@ def main() -> None:
     from relevance_factorizationmachine_amd.fm import FactorizationMachines, FmPlan
     from relevance_factorizationmachine_amd.runtime import DeviceCSR, Runtime, sample_batches
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     device = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(device)
     if world > 1:
@@ -101,7 +294,7 @@ def main() -> None:
 
     shape = synth.SHAPES[args.workload]
     n_train = args.n_train or shape.n_train
-    k, B, K, W = shape.n_factors, args.batch_size, args.steps, args.warmup
+    k, B, K, W, reps = shape.n_factors, args.batch_size, args.steps, args.warmup, max(args.reps, 1)
     lr, seed = 9e-6, 12345  # conf/setting/kuairec.yaml: FM/IPS lr, seed
     if args.strong:
         if B % world:
@@ -111,7 +304,9 @@ def main() -> None:
     if gB > n_train:
         raise SystemExit(f"global batch {gB} exceeds the log ({n_train} rows)")
 
-    train, _ = synth.make_log(shape, "FM", "IPS", seed=0, n_train=n_train, n_val=16)
+    want_fit = rank == 0 and world == 1 and not args.no_extra
+    train, val = synth.make_log(shape, "FM", "IPS", seed=0, n_train=n_train,
+                                n_val=shape.n_val if want_fit else 16)
     X = train["features"]
     n = X.shape[1]
     z = X.nnz / X.shape[0]
@@ -122,8 +317,9 @@ def main() -> None:
     csr = DeviceCSR(rt, X)
     y = rt.upload(train["labels"], dtype=np.float64)
     p = rt.upload(train["pscores"], dtype=np.float64)
+    n_batches = W + reps * K
     t_s = time.perf_counter()
-    ids = sample_batches(n_train, gB, 0, W + K)  # exact resample() ids, same on every rank
+    ids = sample_batches(n_train, gB, 0, n_batches)  # exact resample() ids, same on every rank
     sampler_s = time.perf_counter() - t_s
     d_ids = rt.upload(ids)
     plan = FmPlan(rt, csr, train["labels"], train["pscores"], k, B)
@@ -132,11 +328,27 @@ def main() -> None:
     params = (model.w0.dev.data_ptr(), model.w.dev.data_ptr(), model.V.dev.data_ptr())
 
     transport = None
+    collective = None
     if world == 1:
         def run(first: int, count: int) -> None:
             _lib.check(rt.lib.rfm_fm_train(
                 rt.ctx, plan.handle, *csr_ptrs, d_ids.data_ptr() + first * B * 4, B, count, *params,
                 lr, None, None, None, None, None, 0, 1e-8, None, None))
+    elif args.exchange == "rows":
+        # touched rows only: every rank's gradient rows go to the rank that owns the column
+        # (reduce-scatter by ownership), the owner sums them in rank order and applies, and
+        # the updated rows come back (all-gather) -- SURVEY.md 8e option 1
+        from relevance_factorizationmachine_amd.dist import RowExchange, hip_fm_rows_worker
+
+        ex = RowExchange.for_torch(dist, world, rank, n, k, backend=args.backend)
+        worker = hip_fm_rows_worker(rt, plan, d_ids, gB, model, world, rank, lr, ex)
+        transport = f"torch.distributed/{args.backend} all_to_all_single"
+        collective = ("touched rows: all-to-all of (column, gradient row) lists to the owning rank, "
+                      "owner-side ordered sum + update, all-to-all of the updated rows back")
+
+        def run(first: int, count: int) -> None:
+            for it in range(first, first + count):
+                worker.step(it, gB)
     else:
         grad = rt.empty((n * (k + 1) + 1,), torch.float64)
         all_reduce = None
@@ -158,6 +370,8 @@ def main() -> None:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks or none
             direct = bool(flag.item())
         transport = "rccl-direct" if direct else f"torch.distributed/{args.backend}"
+        collective = (f"all-reduce(sum) of the dense [G_V|g_w|g_w0] buffer, "
+                      f"{8 * (n * (k + 1) + 1) / 1e6:.1f} MB")
 
         def run(first: int, count: int) -> None:
             if direct:
@@ -172,15 +386,19 @@ def main() -> None:
         torch.cuda.synchronize()
 
     run(0, W)
-    fence()
-    t0 = time.perf_counter()
-    run(W, K)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    region = []
+    for r in range(reps):
+        fence()
+        t0 = time.perf_counter()
+        run(W + r * K, K)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        region.append(elapsed)
+    elapsed = float(np.median(region))
     value = K * gB / elapsed
     in_sync = None
     if world > 1:
@@ -215,61 +433,129 @@ def main() -> None:
             "batch_size_per_gpu": B,
             "global_batch": gB,
             "parallelism": f"dp{world}" if world > 1 else "single",
-            "collective": (f"all-reduce(sum) of the dense [G_V|g_w|g_w0] buffer, {8 * (n * (k + 1) + 1) / 1e6:.1f} MB, "
-                           f"{transport}") if world > 1 else None,
+            "collective": f"{collective}, {transport}" if world > 1 else None,
             "replicas_in_sync": in_sync,
+            "timed_regions": reps,
         },
+        "extra": {"rep_ms_per_step": [1e3 * e / K for e in region]},
     }
 
-    if rank == 0 and world == 1:
-        # per-kernel durations with HIP events on the launch stream (same ids, continuing the run)
+    if rank == 0 and world == 1 and not args.pmc_child:
+        # per-kernel durations with HIP events on the launch stream (same ids, one more region)
         ms = (C.c_double * 4)()
         cnt = (C.c_int64 * 4)()
         _lib.check(rt.lib.rfm_profile_begin(rt.ctx))
         run(W, K)
         _lib.check(rt.lib.rfm_profile_end(rt.ctx, ms, cnt))
-        names = ["fm_forward_kernel", "fm_consume_kernel", "fm_finalize_kernel"]
         avg = [ms[i] / max(cnt[i], 1) for i in range(3)]
         fwd_b, upd_b = algorithmic_bytes(z, k)
         alg = [fwd_b * B, upd_b * B, 0.0]
         dom = int(np.argmax(avg))
         achieved = alg[dom] / (avg[dom] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(names[dom], {}).get(str(B))
-            except Exception:
-                traffic = None
-        out["roofline"] = {
-            "bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": avg[dom],
-            "all_kernels_avg_ms": dict(zip(names, avg)),
-            "whole_step": {"algorithmic_bytes": (fwd_b + upd_b) * B, "avg_ms": ms[3] / max(cnt[3], 1),
-                           "achieved": (fwd_b + upd_b) * B / (ms[3] / max(cnt[3], 1) * 1e-3) / 1e9},
-            "note": "V (n*k*8 B) is cache-resident at this size: algorithmic bytes count every touched "
-                    "row as if streamed from HBM, so frac can exceed what the HBM counters show",
-        }
-        out["sampler"] = {"host_exact_mt19937_s_per_batch": sampler_s / (W + K),
-                          "threads": min(os.cpu_count() or 1, 32)}
-        if not args.no_extra and B != 2000:
-            # the reference's own batch size (conf/setting/kuairec.yaml:52)
-            plan2 = FmPlan(rt, csr, train["labels"], train["pscores"], k, 2000)
-            ids2 = rt.upload(sample_batches(n_train, 2000, 0, 200))
+        step_ms = 1e3 * elapsed / K  # the driver-visible step (median region), not the event sum
+        whole_alg = (fwd_b + upd_b) * B
+        whole_achieved = whole_alg / (step_ms * 1e-3) / 1e9
+        info = plan.info()
+        comp = compulsory_bytes(X, ids[W][:B], k, plan.hot_columns(), info["forward_workgroups"])
+        comp_keys = ["forward", "consume", "finalize"]
 
-            def run2(count):
-                _lib.check(rt.lib.rfm_fm_train(rt.ctx, plan2.handle, *csr_ptrs, ids2.data_ptr(), 2000, count,
-                                               *params, lr, None, None, None, None, None, 0, 1e-8, None, None))
-            run2(20)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run2(200)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            out["extra"] = {"batch_2000": {"value": 200 * 2000 / dt, "unit": "examples/s",
-                                           "ms_per_step": 1e3 * dt / 200}}
-            plan2.close()
+        # counter view: measured by this run's child passes; else a committed summary taken
+        # from these very kernel sources; else null with the reason
+        traffic = traffic_all = traffic_source = traffic_error = None
+        if traffic_info and "kernels" in traffic_info:
+            traffic_all = {kname: traffic_info["kernels"].get(kname, {}).get("hbm_bytes") for kname in STEP_KERNELS}
+            traffic_source = {"measured": "live, by this run", "how": traffic_info["how"],
+                              "commit": traffic_info["commit"], "kernels_sha": traffic_info["kernels_sha"],
+                              "seconds": round(traffic_info["seconds"], 1)}
+        else:
+            traffic_error = (traffic_info or {}).get("error", "counter passes skipped (--no-pmc)")
+            old = committed_traffic(B, args.workload)
+            if old:
+                traffic_all = {kname: old["kernels"].get(kname, {}).get("hbm_bytes") for kname in STEP_KERNELS}
+                traffic_source = {"measured": "earlier run, committed", "path": old["path"],
+                                  "commit": old.get("commit"), "kernels_sha": old["kernels_sha"],
+                                  "live_error": traffic_error}
+        if traffic_all:
+            traffic = traffic_all.get(STEP_KERNELS[dom])
+        step_traffic = sum(v for v in (traffic_all or {}).values() if v) if traffic_all else None
+        bound = "latency/L2" if whole_achieved > HBM_PEAK_GBS else "hbm"
+        out["roofline"] = {
+            "bound": bound,
+            "priced_against": "hbm",
+            "kernel": STEP_KERNELS[dom],
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "traffic_source": traffic_source,
+            "traffic_error": None if traffic_source and traffic_source["measured"].startswith("live") else traffic_error,
+            "frac_traffic": (traffic / (avg[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "algorithmic_bytes_per_launch": alg[dom],
+            "compulsory_hbm_bytes": comp[comp_keys[dom]],
+            "frac_compulsory": comp[comp_keys[dom]] / (avg[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "avg_launch_ms": avg[dom],
+            "all_kernels_avg_ms": dict(zip(STEP_KERNELS, avg)),
+            "whole_step": {
+                "ms": step_ms, "event_sum_ms": ms[3] / max(cnt[3], 1),
+                "algorithmic_bytes": whole_alg, "achieved": whole_achieved,
+                "compulsory_hbm_bytes": comp["step"],
+                "traffic": step_traffic,
+                "traffic_per_kernel": traffic_all,
+            },
+            "whole_step_frac": whole_achieved / HBM_PEAK_GBS,
+            "whole_step_frac_compulsory": comp["step"] / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "whole_step_frac_traffic": (step_traffic / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_traffic else None,
+            "compulsory_model": {kk: comp[kk] for kk in ("distinct_columns", "sparse_entries", "hot_columns")},
+            "note": ("algorithmic bytes (SURVEY 8d) count every touched parameter row as if streamed from HBM; "
+                     "V (n*k*8 B = %.1f MB) is L2 / Infinity-Cache resident at this size, so a whole-step "
+                     "fraction above 1 means the HBM model does not bind and the step is bound by gather "
+                     "latency / L2 (bound = latency/L2); compulsory = bytes that must cross HBM from cold "
+                     "caches; traffic = PMC counters" % (n * k * 8 / 1e6)),
+        }
+        out["sampler"] = {"host_exact_mt19937_s_per_batch": sampler_s / n_batches,
+                          "threads": min(os.cpu_count() or 1, 32)}
+        if not args.no_extra:
+            if B != 2000:
+                # the reference's own batch size (conf/setting/kuairec.yaml:52)
+                plan2 = FmPlan(rt, csr, train["labels"], train["pscores"], k, 2000)
+                ids2 = rt.upload(sample_batches(n_train, 2000, 0, 220))
+
+                def run2(first, count):
+                    _lib.check(rt.lib.rfm_fm_train(rt.ctx, plan2.handle, *csr_ptrs,
+                                                   ids2.data_ptr() + first * 2000 * 4, 2000, count,
+                                                   *params, lr, None, None, None, None, None, 0, 1e-8, None, None))
+                run2(0, 20)
+                r2 = []
+                for _ in range(5):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    run2(20, 200)
+                    torch.cuda.synchronize()
+                    r2.append((time.perf_counter() - t0) / 200)
+                dt = float(np.median(r2))
+                _lib.check(rt.lib.rfm_profile_begin(rt.ctx))
+                run2(20, 200)
+                _lib.check(rt.lib.rfm_profile_end(rt.ctx, ms, cnt))
+                out["extra"]["batch_2000"] = {
+                    "value": 2000 / dt, "unit": "examples/s", "ms_per_step": 1e3 * dt,
+                    "kernels_avg_ms": dict(zip(STEP_KERNELS, [ms[i] / max(cnt[i], 1) for i in range(3)])),
+                    "algorithmic_frac": (fwd_b + upd_b) * 2000 / dt / 1e9 / HBM_PEAK_GBS}
+                plan2.close()
+            # variant (A): fit() exactly as the reference runs it (src/fm.py:71-102)
+            fit = {}
+            kw = dict(estimator="IPS", n_factors=k, lr=lr, seed=seed, n_features=n)
+            FactorizationMachines(n_epochs=3, batch_size=2000, **kw).fit(train, val)  # warm
+            for fb, its in ((2000, 200), (65536, 200)):
+                if fb > n_train:
+                    continue
+                m = FactorizationMachines(n_epochs=its, batch_size=fb, **kw)
+                t0 = time.perf_counter()
+                m.fit(train, val)
+                dt = time.perf_counter() - t0
+                fit[f"batch_{fb}"] = {"iterations": its, "ms_per_iteration": 1e3 * dt / its,
+                                      "value": its * fb / dt, "unit": "examples/s"}
+            out["extra"]["fit_wall"] = {
+                **fit, "what": (f"FactorizationMachines.fit(train N={n_train}, val N={val['features'].shape[0]}) wall: "
+                                "exact sampler, uploads, plan build, and per iteration step + train-loss forward "
+                                "(new parameters, same batch) + validation-loss forward")}
         if not args.no_cpu_baseline:
             v, steps_done, dt = cpu_baseline(train, ids[W:], k, lr, seed)
             out["cpu_baseline"] = {
@@ -279,6 +565,13 @@ def main() -> None:
                            "per-factor loop, row gather X[ids] included, sampler excluded; SciPy sparse "
                            f"kernels are single-threaded (host has {os.cpu_count()} cpus)"),
             }
+            if not args.no_extra:
+                out["cpu_baseline"]["fit_wall"] = {
+                    "batch_2000": cpu_fit_wall(train, val, k, lr, seed, 2000, 20),
+                    "batch_65536": cpu_fit_wall(train, val, k, lr, seed, 65536, 3) if n_train >= 65536 else None,
+                    "what": "oracle/cpu_ref.fm_fit(form='refstruct'): resample + step + both loss forwards "
+                            "per iteration, as src/fm.py:71-102",
+                }
     fence()
     plan.close()
     if rank == 0:

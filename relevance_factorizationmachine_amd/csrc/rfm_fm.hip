@@ -176,9 +176,11 @@ struct rfm_fm_plan {
   int32_t k = 0;
   int32_t n_win = 0, n_cross_short = 0, n_cross_long = 0, n_hot = 0;
   int64_t step = 0;  // stamps the carries of a step
+  int32_t fwd_grid_max = 0;  // forward workgroups of a max_batch step (= hot-sum slabs)
   rfm::DevBuf ent, rows, slot_t, slots, win, cross, carry_idx, carries, Q, err, hot_cols,
       hot_slab, hot_part, err_partial;
   rfm::DevBuf loss_rows;  // rfm_fm_train: per-workgroup loss partials of a run of iterations
+  std::vector<int32_t> h_hot_cols;  // host copy of hot_cols (rfm_fm_plan_hot_columns)
   size_t device_bytes() const {
     return ent.bytes + rows.bytes + slot_t.bytes + slots.bytes + win.bytes + cross.bytes +
            carry_idx.bytes + carries.bytes + Q.bytes + err.bytes + hot_cols.bytes +
@@ -595,6 +597,8 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
     plan->n_cross_short = int32_t(cross_short.size());
     plan->n_cross_long = int32_t(cross_long.size());
     plan->n_hot = int32_t(hot_cols.size());
+    plan->h_hot_cols = hot_cols;
+    plan->fwd_grid_max = forward_geom(ctx, max_batch, shp, true).grid;
     upload(plan->ent, ent.get(), (nz + 1) * sizeof(Entry), ctx->stream);
     upload(plan->rows, rows.get(), nr * sizeof(RowRec), ctx->stream);
     upload(plan->slots, slots.get(), (ns + 256) * sizeof(SlotRec), ctx->stream);
@@ -636,14 +640,25 @@ int32_t rfm_fm_plan_destroy(rfm_fm_plan* plan) {
   });
 }
 
-int32_t rfm_fm_plan_info(const rfm_fm_plan* plan, int64_t* h_out5) {
+int32_t rfm_fm_plan_info(const rfm_fm_plan* plan, int64_t* h_out8) {
   return guarded([&] {
-    RFM_REQUIRE(plan && h_out5, "null pointer");
-    h_out5[0] = plan->n_win;
-    h_out5[1] = plan->n_cross_short + plan->n_cross_long;
-    h_out5[2] = plan->n_hot;
-    h_out5[3] = plan->nnz;
-    h_out5[4] = int64_t(plan->device_bytes());
+    RFM_REQUIRE(plan && h_out8, "null pointer");
+    h_out8[0] = plan->n_win;
+    h_out8[1] = plan->n_cross_short + plan->n_cross_long;
+    h_out8[2] = plan->n_hot;
+    h_out8[3] = plan->nnz;
+    h_out8[4] = int64_t(plan->device_bytes());
+    h_out8[5] = plan->fwd_grid_max;
+    h_out8[6] = plan->n_slots;
+    h_out8[7] = 0;
+  });
+}
+
+int32_t rfm_fm_plan_hot_columns(const rfm_fm_plan* plan, int32_t* h_out, int32_t capacity) {
+  return guarded([&] {
+    RFM_REQUIRE(plan && (h_out || capacity == 0), "null pointer");
+    RFM_REQUIRE(capacity >= plan->n_hot, "capacity %d < %d hot columns", capacity, plan->n_hot);
+    std::copy(plan->h_hot_cols.begin(), plan->h_hot_cols.end(), h_out);
   });
 }
 

@@ -41,10 +41,15 @@ class FmPlan:
         self.handle = handle
 
     def info(self) -> dict:
-        out = np.zeros(5, dtype=np.int64)
+        out = np.zeros(8, dtype=np.int64)
         _lib.check(self.rt.lib.rfm_fm_plan_info(self.handle, out.ctypes.data))
-        return dict(zip(("windows", "crossing_columns", "hot_columns", "nnz", "device_bytes"),
-                        (int(v) for v in out)))
+        return dict(zip(("windows", "crossing_columns", "hot_columns", "nnz", "device_bytes",
+                         "forward_workgroups", "slots"), (int(v) for v in out)))
+
+    def hot_columns(self) -> np.ndarray:
+        out = np.zeros(max(self.info()["hot_columns"], 1), dtype=np.int32)
+        _lib.check(self.rt.lib.rfm_fm_plan_hot_columns(self.handle, out.ctypes.data, out.shape[0]))
+        return out[: self.info()["hot_columns"]]
 
     def close(self) -> None:
         if self.handle is not None:

@@ -161,6 +161,50 @@ int32_t rfm_fm_grad(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
 int32_t rfm_fm_apply(rfm_ctx* ctx, double* d_w0, double* d_w, double* d_V,
                      const double* d_grad, int64_t n_features, int32_t n_factors, double lr);
 
+/* ---- FM: touched-row gradients -----------------------------
+ * The reference writes only the rows of V whose gradient is non-zero
+ * (src/fm.py:183-187): the columns the batch touches.  rfm_fm_grad_rows computes
+ * the same batch-SUM gradients as rfm_fm_grad for rows d_row_ids[0..batch) (a
+ * rank's shard; batch may be 0) but returns them as a list of RECORDS, ascending
+ * by column, of n_factors + 2 doubles each:
+ *     [column (exact in a double), G_V[column, 0..k), g_w[column]]
+ * d_rows has room for cap_rows records; *d_n_rows receives the true number (a
+ * caller that sees *d_n_rows > cap_rows got only the first cap_rows), *d_gw0
+ * the shard's g_w0.  Optional owner ranges for the exchange: d_range_lo[n_ranges]
+ * (ascending first columns, n_ranges <= 64) -> d_range_bounds[n_ranges + 1]:
+ * position in the list of the first record with column >= range_lo[i], and the
+ * total.  Nothing of size n_features is cleared or moved per call: the kernels
+ * stamp the columns they write, and a count / scan / gather over the stamps
+ * builds the list. */
+int32_t rfm_fm_grad_rows(rfm_ctx* ctx, rfm_fm_plan* plan, const int32_t* d_row_ids, int64_t batch,
+                         const double* d_w0, const double* d_w, const double* d_V, double* d_rows,
+                         int64_t cap_rows, int32_t* d_n_rows, double* d_gw0,
+                         const int32_t* d_range_lo, int32_t n_ranges, int32_t* d_range_bounds);
+/* theta -= lr * g for the records of such a list (utils/optimizer.py:56-64 with a
+ * row index): V[column,:] -= lr * G_V row, w[column] -= lr * g_w; w0 -= lr * *d_gw0
+ * when d_gw0 is given.  The count is read on the device (min(*d_n_rows, cap_rows)). */
+int32_t rfm_fm_apply_rows(rfm_ctx* ctx, const double* d_rows, const int32_t* d_n_rows,
+                          int64_t cap_rows, const double* d_gw0, double* d_w0, double* d_w,
+                          double* d_V, int64_t n_features, int32_t n_factors, double lr);
+/* Owner side of the exchange.  d_rows holds n_segments lists back to back, segment
+ * s = records d_seg_ptr[s] .. d_seg_ptr[s+1] (what rank s sent; ascending by column;
+ * total_rows = d_seg_ptr[n_segments], passed on the host too to size the launch).
+ * Records of one column are added in segment (= rank) order, the row is updated from
+ * the owner's d_V / d_w (read only), and d_out_rows -- same number of records -- holds
+ * [column, V_new[column,:], w_new[column]] at the position of the column's first
+ * record and column = -1 at the positions of its other records. */
+int32_t rfm_fm_reduce_rows(rfm_ctx* ctx, const double* d_rows, const int32_t* d_seg_ptr,
+                           int32_t n_segments, int64_t total_rows, const double* d_w,
+                           const double* d_V, int64_t n_features, int32_t n_factors, double lr,
+                           double* d_out_rows);
+/* Store updated rows ([column, V_new row, w_new]; column < 0 = skip; columns distinct)
+ * into a replica, and w0 -= lr * (d_gw0_parts[0] + d_gw0_parts[part_stride] + ...,
+ * n_parts terms in that order) when n_parts > 0. */
+int32_t rfm_fm_set_rows(rfm_ctx* ctx, const double* d_rows, int64_t n_rows,
+                        const double* d_gw0_parts, int32_t n_parts, int64_t part_stride,
+                        double* d_w0, double* d_w, double* d_V, int64_t n_features,
+                        int32_t n_factors, double lr);
+
 /* ---- FM: the fit() loop --------------------------------------------------
  * Replaces the body of FactorizationMachines.fit (src/fm.py:71-102) for
  * iterations [0, n_iters): step on batch d_ids[it*batch ...], then the train

@@ -19,6 +19,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("RFM_LIB_PATH") or os.path.join(PKG_DIR, "librfm_hip.so")
 SOURCES = ["rfm_capi.hip", "rfm_fm.hip", "rfm_mf.hip", "rfm_eval.hip", "rfm_host.cpp", "rfm_comm.cpp"]
 HEADERS = [os.path.join(CSRC, "rfm_common.h"), os.path.join(CSRC, "rfm_fm_kernels.hpp"),
+           os.path.join(CSRC, "rfm_fm_rows.hpp"),
            os.path.join(os.path.dirname(PKG_DIR), "include", "rfm_hip.h")]
 
 RFM_OK, RFM_ERR_BAD_ARG, RFM_ERR_HIP, RFM_ERR_NO_DEVICE, RFM_ERR_INTERNAL = range(5)
@@ -89,6 +90,10 @@ SIGNATURES = {
     "rfm_fm_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f64],
     "rfm_fm_grad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "rfm_fm_apply": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64],
+    "rfm_fm_grad_rows": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp],
+    "rfm_fm_apply_rows": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _f64],
+    "rfm_fm_reduce_rows": [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _i64, _i32, _f64, _vp],
+    "rfm_fm_set_rows": [_vp, _vp, _i64, _vp, _i32, _i64, _vp, _vp, _vp, _i64, _i32, _f64],
     "rfm_fm_train": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _f64,
                      _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp],
     "rfm_fm_train_dp": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f64, _vp],

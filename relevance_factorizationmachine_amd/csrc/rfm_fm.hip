@@ -51,6 +51,7 @@
 
 #include "rfm_common.h"
 #include "rfm_fm_kernels.hpp"
+#include "rfm_fm_rows.hpp"
 
 static_assert(RFM_MAX_FACTORS <= 1024, "fm_finalize_kernel's LDS totals hold 1024+2 values");
 
@@ -181,6 +182,11 @@ struct rfm_fm_plan {
       hot_slab, hot_part, err_partial;
   rfm::DevBuf loss_rows;  // rfm_fm_train: per-workgroup loss partials of a run of iterations
   std::vector<int32_t> h_hot_cols;  // host copy of hot_cols (rfm_fm_plan_hot_columns)
+  // touched-row gradients (rfm_fm_grad_rows), allocated on first use: the gradient table
+  // [G_V | g_w | g_w0] indexed by column, never cleared; touch[col] == touch_seq marks the
+  // rows of the current step
+  rfm::DevBuf row_table, touch, chunk_cnt;
+  int32_t touch_seq = 0;
   size_t device_bytes() const {
     return ent.bytes + rows.bytes + slot_t.bytes + slots.bytes + win.bytes + cross.bytes +
            carry_idx.bytes + carries.bytes + Q.bytes + err.bytes + hot_cols.bytes +
@@ -215,7 +221,8 @@ void check_step_args(const rfm_fm_plan* plan, const void* indptr, const void* in
 void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
                   const int32_t* d_indices, const double* d_values, const double* d_y,
                   const double* d_pscore, const int32_t* d_row_ids, int64_t batch, double* d_w0,
-                  double* d_w, double* d_V, double lr, double* d_grad) {
+                  double* d_w, double* d_V, double lr, double* d_grad, int32_t* d_touch = nullptr,
+                  int32_t touch_id = 0) {
   const int k = plan->k;
   const Shape s = shape_for(k);
   (void)d_indptr;
@@ -249,7 +256,7 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
     launch_forward(ctx, f, geom);
   ctx->prof_mark();
 
-  if (d_grad) {
+  if (d_grad && !d_touch) {  // dense gradient: every element is written
     const size_t bytes = (size_t(plan->n_features) * (k + 1) + 1) * sizeof(double);
     RFM_HIP_CHECK(hipMemsetAsync(d_grad, 0, bytes, ctx->stream));
   }
@@ -271,6 +278,8 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
     c.carries = plan->carries.as<double>();
     c.stamp = stamp;
     c.grad = d_grad;
+    c.touch = d_touch;
+    c.touch_id = touch_id;
     const int wpb = (kBlock / kWave) * (kWave / s.lpr);  // one window per lane group
     c.nb_win = (plan->n_win + wpb - 1) / wpb;
     c.n_hot = plan->n_hot;
@@ -309,6 +318,8 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   fa.V = d_V;
   fa.lr = lr;
   fa.grad = d_grad;
+  fa.touch = d_touch;
+  fa.touch_id = touch_id;
   {
     const int gpb = kBlock / s.lpr;
     const int nb_cross = (plan->n_hot + plan->n_cross_short + gpb - 1) / gpb;
@@ -698,6 +709,112 @@ int32_t rfm_fm_apply(rfm_ctx* ctx, double* d_w0, double* d_w, double* d_V,
         int(std::min<int64_t>((total + kBlock - 1) / kBlock, int64_t(ctx->n_cu) * 16));
     hipLaunchKernelGGL(fm_apply_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_V, d_w, d_w0,
                        d_grad, nk, n_features, lr);
+    RFM_HIP_CHECK(hipGetLastError());
+  });
+}
+
+// ---------------------------------------------------------------------------
+// touched-row gradients and their exchange (SURVEY.md 8e option 1)
+// ---------------------------------------------------------------------------
+int32_t rfm_fm_grad_rows(rfm_ctx* ctx, rfm_fm_plan* plan, const int32_t* d_row_ids, int64_t batch,
+                         const double* d_w0, const double* d_w, const double* d_V, double* d_rows,
+                         int64_t cap_rows, int32_t* d_n_rows, double* d_gw0,
+                         const int32_t* d_range_lo, int32_t n_ranges, int32_t* d_range_bounds) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx && plan && d_w0 && d_w && d_V && d_rows && d_n_rows && d_gw0, "null pointer");
+    RFM_REQUIRE(batch >= 0 && batch <= plan->max_batch, "batch=%lld outside 0..max_batch=%lld",
+                (long long)batch, (long long)plan->max_batch);
+    RFM_REQUIRE(batch == 0 || d_row_ids, "null row ids");
+    RFM_REQUIRE(cap_rows >= 0, "negative capacity");
+    RFM_REQUIRE(n_ranges >= 0 && n_ranges <= kMaxRanges, "n_ranges=%d outside 0..%d", n_ranges,
+                kMaxRanges);
+    RFM_REQUIRE(n_ranges == 0 || (d_range_lo && d_range_bounds), "null range arrays");
+    const int64_t n = plan->n_features;
+    const int k = plan->k;
+    if (!plan->row_table.p) {
+      plan->row_table.alloc((size_t(n) * size_t(k + 1) + 1) * sizeof(double));
+      plan->touch.alloc(size_t(n) * 4);
+      plan->chunk_cnt.alloc(size_t((n + kTouchChunk - 1) / kTouchChunk) * 4);
+      plan->touch_seq = 0;
+    }
+    if (plan->touch_seq == 0 || plan->touch_seq == INT32_MAX) {
+      RFM_HIP_CHECK(hipMemsetAsync(plan->touch.p, 0, plan->touch.bytes, ctx->stream));
+      plan->touch_seq = 0;
+    }
+    const int32_t id = ++plan->touch_seq;
+    double* table = plan->row_table.as<double>();
+    int32_t* touch = plan->touch.as<int32_t>();
+    if (batch > 0) {
+      enqueue_step(ctx, plan, nullptr, nullptr, nullptr, nullptr, nullptr, d_row_ids, batch,
+                   const_cast<double*>(d_w0), const_cast<double*>(d_w), const_cast<double*>(d_V),
+                   0.0, table, touch, id);
+    } else {  // an empty shard touches nothing
+      RFM_HIP_CHECK(hipMemsetAsync(table + n * (k + 1), 0, sizeof(double), ctx->stream));
+    }
+    const int n_chunks = int((n + kTouchChunk - 1) / kTouchChunk);
+    int32_t* chunk = plan->chunk_cnt.as<int32_t>();
+    hipLaunchKernelGGL(touch_count_kernel, dim3(n_chunks), dim3(kBlock), 0, ctx->stream, touch, id,
+                       n, chunk);
+    hipLaunchKernelGGL(touch_scan_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, touch, id, n,
+                       chunk, n_chunks, d_n_rows, n_ranges ? d_range_lo : nullptr, int(n_ranges),
+                       d_range_bounds);
+    hipLaunchKernelGGL(touch_gather_kernel, dim3(n_chunks), dim3(kBlock), 0, ctx->stream, touch,
+                       id, n, k, chunk, table, d_rows, cap_rows, d_gw0);
+    RFM_HIP_CHECK(hipGetLastError());
+  });
+}
+
+int32_t rfm_fm_apply_rows(rfm_ctx* ctx, const double* d_rows, const int32_t* d_n_rows,
+                          int64_t cap_rows, const double* d_gw0, double* d_w0, double* d_w,
+                          double* d_V, int64_t n_features, int32_t n_factors, double lr) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx && d_rows && d_n_rows && d_w0 && d_w && d_V, "null pointer");
+    RFM_REQUIRE(n_features >= 1 && n_factors >= 1 && cap_rows >= 0, "bad shape");
+    const int wpb = kBlock / kWave;
+    const int grid = int(std::max<int64_t>(
+        1, std::min<int64_t>((cap_rows + wpb - 1) / wpb, int64_t(ctx->n_cu) * 8)));
+    hipLaunchKernelGGL(rows_apply_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_rows,
+                       d_n_rows, cap_rows, d_gw0, d_w0, d_w, d_V, n_features, int(n_factors), lr);
+    RFM_HIP_CHECK(hipGetLastError());
+  });
+}
+
+int32_t rfm_fm_reduce_rows(rfm_ctx* ctx, const double* d_rows, const int32_t* d_seg_ptr,
+                           int32_t n_segments, int64_t total_rows, const double* d_w,
+                           const double* d_V, int64_t n_features, int32_t n_factors, double lr,
+                           double* d_out_rows) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx && d_seg_ptr && d_w && d_V, "null pointer");
+    RFM_REQUIRE(n_segments >= 1 && n_segments <= kWave, "n_segments=%d outside 1..%d", n_segments,
+                kWave);
+    RFM_REQUIRE(n_features >= 1 && n_factors >= 1 && total_rows >= 0, "bad shape");
+    if (total_rows == 0) return;
+    RFM_REQUIRE(d_rows && d_out_rows, "null record lists");
+    const int wpb = kBlock / kWave;
+    const int grid = int(std::min<int64_t>((total_rows + wpb - 1) / wpb, int64_t(ctx->n_cu) * 8));
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_rows,
+                       d_seg_ptr, int(n_segments), d_w, d_V, n_features, int(n_factors), lr,
+                       d_out_rows);
+    RFM_HIP_CHECK(hipGetLastError());
+  });
+}
+
+int32_t rfm_fm_set_rows(rfm_ctx* ctx, const double* d_rows, int64_t n_rows,
+                        const double* d_gw0_parts, int32_t n_parts, int64_t part_stride,
+                        double* d_w0, double* d_w, double* d_V, int64_t n_features,
+                        int32_t n_factors, double lr) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx && d_w0 && d_w && d_V, "null pointer");
+    RFM_REQUIRE(n_features >= 1 && n_factors >= 1 && n_rows >= 0 && n_parts >= 0, "bad shape");
+    RFM_REQUIRE(n_rows == 0 || d_rows, "null record list");
+    RFM_REQUIRE(n_parts == 0 || d_gw0_parts, "null g_w0 partials");
+    if (n_rows == 0 && n_parts == 0) return;
+    const int wpb = kBlock / kWave;
+    const int grid = int(std::max<int64_t>(
+        1, std::min<int64_t>((n_rows + wpb - 1) / wpb, int64_t(ctx->n_cu) * 8)));
+    hipLaunchKernelGGL(rows_set_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_rows, n_rows,
+                       n_parts ? d_gw0_parts : nullptr, int(n_parts), part_stride, d_w0, d_w, d_V,
+                       n_features, int(n_factors), lr);
     RFM_HIP_CHECK(hipGetLastError());
   });
 }

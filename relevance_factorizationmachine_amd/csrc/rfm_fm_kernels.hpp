@@ -599,6 +599,8 @@ struct ConsArgs {
   double* carries;  // [n_win*2][k+3]: M[0..k), sum coef, sum coef*x, step stamp
   double stamp;     // id of this step (a carry row is valid iff its stamp matches)
   double* grad;     // nullable: grad mode -> [G_V | g_w | g_w0]
+  int32_t* touch;   // nullable (grad mode): touch[col] = touch_id for every column written
+  int32_t touch_id;
   // hot columns ride in the same launch: the workgroups after the windows reduce
   // the forward's slabs (independent of the sparse class, so the two overlap)
   int32_t nb_win;   // workgroups that process windows
@@ -627,7 +629,8 @@ struct ColAcc {
 template <int LPR, int VEC, int NC>
 __device__ inline void apply_column(const ColAcc<VEC, NC>& acc, const Pack<VEC> (&vold)[NC],
                                     int32_t col, double* V, double* w, double* grad, int64_t n,
-                                    int k, double lr, int l) {
+                                    int k, double lr, int l, int32_t* touch = nullptr,
+                                    int32_t touch_id = 0) {
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int f = (c * LPR + l) * VEC;
@@ -646,10 +649,12 @@ __device__ inline void apply_column(const ColAcc<VEC, NC>& acc, const Pack<VEC> 
     }
   }
   if (l == 0) {
-    if (grad)
+    if (grad) {
       grad[n * k + col] = -acc.gw;
-    else
+      if (touch) touch[col] = touch_id;  // touched-row mode: the row is valid for this step
+    } else {
       w[col] += lr * acc.gw;
+    }
   }
 }
 
@@ -687,7 +692,8 @@ __device__ __forceinline__ void emit_column(const ColAcc<VEC, NC>& acc,
       row[k + 2] = a.stamp;
     }
   } else {
-    apply_column<LPR, VEC, NC>(acc, vold, cur, a.V, a.w, a.grad, a.n, k, a.lr, l);
+    apply_column<LPR, VEC, NC>(acc, vold, cur, a.V, a.w, a.grad, a.n, k, a.lr, l, a.touch,
+                               a.touch_id);
   }
 }
 
@@ -852,6 +858,8 @@ struct FinArgs {
   double* V;
   double lr;
   double* grad;  // nullable
+  int32_t* touch;  // nullable (grad mode): see ConsArgs
+  int32_t touch_id;
 };
 
 // blocks [0, nb_cross): hot columns (partial rows from fm_consume_kernel) and short
@@ -891,7 +899,8 @@ __global__ __launch_bounds__(kBlock) void fm_finalize_kernel(FinArgs a, int nb_c
         acc.gw += row[p * (k + 2) + k];
         acc.d += row[p * (k + 2) + k + 1];
       }
-      apply_column<LPR, VEC, NC>(acc, vold, col, a.V, a.w, a.grad, a.n, k, a.lr, l);
+      apply_column<LPR, VEC, NC>(acc, vold, col, a.V, a.w, a.grad, a.n, k, a.lr, l, a.touch,
+                                 a.touch_id);
       return;
     }
     const CrossCol cc = a.cross[ci - a.n_hot];
@@ -939,7 +948,9 @@ __global__ __launch_bounds__(kBlock) void fm_finalize_kernel(FinArgs a, int nb_c
         acc.d += ok ? dd[u] : 0.0;
       }
     }
-    if (any) apply_column<LPR, VEC, NC>(acc, vold, cc.col, a.V, a.w, a.grad, a.n, k, a.lr, l);
+    if (any)
+      apply_column<LPR, VEC, NC>(acc, vold, cc.col, a.V, a.w, a.grad, a.n, k, a.lr, l, a.touch,
+                                 a.touch_id);
     return;
   }
   const int lb = b - nb_cross;
@@ -957,10 +968,12 @@ __global__ __launch_bounds__(kBlock) void fm_finalize_kernel(FinArgs a, int nb_c
         a.V[at] += a.lr * (tot[f] - d * a.V[at]);
     }
     if (threadIdx.x == 0) {
-      if (a.grad)
+      if (a.grad) {
         a.grad[a.n * k + col] = -gw;
-      else
+        if (a.touch) a.touch[col] = a.touch_id;
+      } else {
         a.w[col] += a.lr * gw;
+      }
     }
     return;
   }

@@ -118,3 +118,180 @@ def hip_fm_train_dp(rt, plan, d_ids, global_batch: int, first: int, count: int, 
         rt.ctx, plan.handle, d_ids.data_ptr() + first * global_batch * 4, global_batch, lo, hi, count,
         model.w0.dev.data_ptr(), model.w.dev.data_ptr(), model.V.dev.data_ptr(), float(lr),
         grad.data_ptr()))
+
+
+# ---------------------------------------------------------------------------
+# touched-row exchange (option 1: feature-range ownership)
+# ---------------------------------------------------------------------------
+def owner_ranges(n_features: int, world: int):
+    """First column of every rank's range (ascending, ``world`` entries): rank r owns
+    columns ``[lo[r], lo[r+1])`` (the last range ends at ``n_features``)."""
+    import numpy as np
+
+    return np.array([n_features * r // world for r in range(world)], dtype=np.int32)
+
+
+class TorchRowComm:
+    """The three collectives of one exchange over ``torch.distributed``.
+
+    ``stage_host`` moves the payloads through host memory (gloo; also how two ranks that
+    share one GPU in the tests talk); with backend nccl (= RCCL over xGMI) they stay on the
+    device.  Records are rows of ``width`` float64."""
+
+    def __init__(self, dist, world: int, rank: int, width: int, stage_host: bool):
+        self.dist, self.world, self.rank, self.width, self.stage_host = dist, world, rank, width, stage_host
+
+    def _wire(self, t):
+        return t.cpu() if self.stage_host else t
+
+    def gather_meta(self, meta):
+        """all-gather of one small float64 vector per rank -> host ndarray [world][len]."""
+        import torch
+
+        m = self._wire(meta)
+        out = [torch.empty_like(m) for _ in range(self.world)]
+        self.dist.all_gather(out, m)
+        return torch.stack(out).cpu().numpy()
+
+    def all_to_all_rows(self, rows, send_counts, recv_counts):
+        """Records [sum(send_counts)][width] cut by destination -> records [sum(recv_counts)][width]
+        ordered by source rank."""
+        import torch
+
+        src = self._wire(rows).reshape(-1)
+        out = torch.empty(int(sum(recv_counts)) * self.width, dtype=src.dtype, device=src.device)
+        self.dist.all_to_all_single(out, src[: int(sum(send_counts)) * self.width],
+                                    [int(c) * self.width for c in recv_counts],
+                                    [int(c) * self.width for c in send_counts])
+        out = out.reshape(-1, self.width)
+        return out.to(rows.device) if self.stage_host else out
+
+    def all_gather_rows(self, rows, counts):
+        """Every rank's record list (``counts[r]`` records from rank r) -> all of them, by rank."""
+        import torch
+
+        mine = self._wire(rows).reshape(-1)[: int(counts[self.rank]) * self.width]
+        parts = [torch.empty(int(c) * self.width, dtype=mine.dtype, device=mine.device) for c in counts]
+        if len({int(c) for c in counts}) == 1:
+            self.dist.all_gather(parts, mine)
+        else:
+            self._all_gather_v(parts, mine)
+        out = torch.cat(parts).reshape(-1, self.width)
+        return out.to(rows.device) if self.stage_host else out
+
+    def _all_gather_v(self, parts, mine):
+        # lists of different lengths: one broadcast per source rank
+        for r in range(self.world):
+            if r == self.rank:
+                parts[r].copy_(mine)
+            if parts[r].numel():
+                self.dist.broadcast(parts[r], src=r)
+
+
+class RowExchangeStep:
+    """One data-parallel FM step that moves only the touched rows.
+
+    Parameters are replicated; rank r owns the columns ``[lo[r], lo[r+1])``.  Per step:
+
+    1. ``grad_rows_fn(lo, hi, it)`` -> this rank's gradient records of batch rows [lo, hi) of
+       iteration ``it`` -- ``(rows [cnt][k+2] ascending by column, bounds int[world+1]``
+       = position of each owner range in the list, ``g_w0 partial)``;
+    2. all-gather of ``[bounds | g_w0]`` (one small vector per rank): every rank now knows
+       every transfer size of the step and all partial g_w0;
+    3. all-to-all: each record goes to the rank that owns its column;
+    4. ``reduce_fn(recv, seg_ptr)``: the owner adds the records of a column in RANK ORDER and
+       updates its row -> ``[column, V_new, w_new]`` (column -1 at the positions of a column's
+       other records, so list sizes are known beforehand);
+    5. all-gather of the updated rows; ``set_rows_fn(all_rows, gw0_parts)`` stores them into
+       the local replica and applies ``w0 -= lr * sum(gw0_parts)`` (rank order).
+
+    Every replica ends the step with identical parameters, bit for bit: each row is computed
+    once, by its owner, and copied.  The arithmetic is injected (HIP kernels in
+    ``hip_fm_rows_worker``; NumPy from the oracle in the CPU tests)."""
+
+    def __init__(self, world: int, rank: int, comm, grad_rows_fn: Callable, reduce_fn: Callable,
+                 set_rows_fn: Callable):
+        self.world, self.rank, self.comm = world, rank, comm
+        self.grad_rows_fn, self.reduce_fn, self.set_rows_fn = grad_rows_fn, reduce_fn, set_rows_fn
+        self.last_counts = None  # records sent per destination in the last step (diagnostics)
+
+    def step(self, it: int, global_batch: int) -> None:
+        import numpy as np
+
+        lo, hi = shard_bounds(global_batch, self.world, self.rank)
+        rows, meta = self.grad_rows_fn(lo, hi, it)  # meta: float64 [world + 2] = bounds | g_w0
+        allmeta = self.comm.gather_meta(meta)  # host [world][world + 2]; the step's one host sync
+        bounds = np.rint(allmeta[:, : self.world + 1]).astype(np.int64)
+        send = np.diff(bounds[self.rank])
+        recv = np.array([bounds[s, self.rank + 1] - bounds[s, self.rank] for s in range(self.world)])
+        self.last_counts = send
+        got = self.comm.all_to_all_rows(rows, send, recv)
+        seg_ptr = np.concatenate([[0], np.cumsum(recv)]).astype(np.int32)
+        upd = self.reduce_fn(got, seg_ptr)
+        # rank r emits as many (padded) records as it received
+        out_counts = [int(sum(bounds[s, r + 1] - bounds[s, r] for s in range(self.world)))
+                      for r in range(self.world)]
+        everything = self.comm.all_gather_rows(upd, out_counts)
+        self.set_rows_fn(everything, allmeta[:, self.world + 1])
+
+
+def hip_fm_rows_worker(rt, plan, d_ids, global_batch: int, model, world: int, rank: int, lr: float,
+                       comm, cap_rows: int = 0) -> RowExchangeStep:
+    """Bind ``RowExchangeStep`` to the HIP kernels (``rfm_fm_grad_rows``, ``rfm_fm_reduce_rows``,
+    ``rfm_fm_set_rows``).  ``d_ids`` holds the GLOBAL batches ``(n_iters, global_batch)`` int32
+    on the device; ``cap_rows`` bounds a rank's record list (default: every column)."""
+    import numpy as np
+    import torch
+
+    from . import _lib
+
+    n, k = model.n_features, model.n_factors
+    width = k + 2
+    cap = int(cap_rows) if cap_rows else n
+    params = (model.w0.dev.data_ptr(), model.w.dev.data_ptr(), model.V.dev.data_ptr())
+    rows = rt.empty((cap, width), torch.float64)
+    n_rows = rt.empty((1,), torch.int32)
+    meta = rt.empty((world + 2,), torch.float64)
+    bounds = rt.empty((world + 1,), torch.int32)
+    gw0 = rt.empty((1,), torch.float64)
+    range_lo = rt.upload(owner_ranges(n, world))
+
+    def grad_rows_fn(lo: int, hi: int, it: int):
+        ids_ptr = d_ids.data_ptr() + (it * global_batch + lo) * 4
+        _lib.check(rt.lib.rfm_fm_grad_rows(
+            rt.ctx, plan.handle, ids_ptr, hi - lo, *params, rows.data_ptr(), cap, n_rows.data_ptr(),
+            gw0.data_ptr(), range_lo.data_ptr(), world, bounds.data_ptr()))
+        meta[: world + 1] = bounds
+        meta[world + 1] = gw0[0]
+        return rows, meta
+
+    def reduce_fn(got, seg_ptr):
+        total = int(seg_ptr[-1])
+        out = rt.empty((max(total, 1), width), torch.float64)
+        d_seg = rt.upload(seg_ptr)
+        _lib.check(rt.lib.rfm_fm_reduce_rows(
+            rt.ctx, got.data_ptr() if total else None, d_seg.data_ptr(), world, total, params[1], params[2],
+            n, k, float(lr), out.data_ptr() if total else None))
+        return out
+
+    def set_rows_fn(everything, gw0_parts):
+        parts = rt.upload(np.ascontiguousarray(gw0_parts, dtype=np.float64))
+        cnt = int(everything.shape[0])
+        _lib.check(rt.lib.rfm_fm_set_rows(
+            rt.ctx, everything.data_ptr() if cnt else None, cnt, parts.data_ptr(), world, 1, *params,
+            n, k, float(lr)))
+
+    return RowExchangeStep(world, rank, comm, grad_rows_fn, reduce_fn, set_rows_fn)
+
+
+class RowExchange:
+    """Factory for the transport of ``RowExchangeStep`` (kept apart so bench.py and the tests
+    pick the same wiring)."""
+
+    @staticmethod
+    def for_torch(dist, world: int, rank: int, n_features: int, n_factors: int, backend: str = "nccl",
+                  stage_host=None) -> TorchRowComm:
+        del n_features
+        if stage_host is None:
+            stage_host = backend != "nccl"
+        return TorchRowComm(dist, world, rank, n_factors + 2, stage_host)

@@ -88,3 +88,138 @@ def test_two_rank_data_parallel_equals_single_process(tmp_path):
     # replicas stay bitwise identical: same all-reduced gradient, same apply
     np.testing.assert_array_equal(outs[0]["V"], outs[1]["V"])
     np.testing.assert_array_equal(outs[0]["w"], outs[1]["w"])
+
+
+# ---------------------------------------------------------------------------
+# touched-row exchange (SURVEY.md 8e option 1): RowExchangeStep + TorchRowComm are the
+# product code; the arithmetic plugged in is NumPy from the oracle
+# ---------------------------------------------------------------------------
+def _np_grad_rows(X, y, p, w0, w, V, rows_idx, lo_cols, world):
+    """Oracle gradient of the given rows as the record list rfm_fm_grad_rows emits."""
+    n, k = V.shape
+    if len(rows_idx) == 0:
+        return np.zeros((0, k + 2)), np.zeros(world + 1), 0.0
+    Xb = X[rows_idx]
+    _, g_w0, g_w, G_V = cpu_ref.fm_gradients(Xb, y[rows_idx], p[rows_idx], w0, w, V)
+    cols = np.unique(Xb.indices)
+    rec = np.concatenate([cols[:, None].astype(np.float64), G_V[cols], g_w[cols, None]], axis=1)
+    bounds = np.concatenate([np.searchsorted(cols, lo_cols), [len(cols)]]).astype(np.float64)
+    return rec, bounds, float(g_w0)
+
+
+def _np_reduce_rows(got, seg_ptr, w, V, lr):
+    """Owner-side sum in segment (rank) order + update, in the layout rfm_fm_reduce_rows emits."""
+    out = np.full_like(got, 0.0)
+    out[:, 0] = -1.0
+    first = {}
+    acc = {}
+    for s in range(len(seg_ptr) - 1):
+        for i in range(seg_ptr[s], seg_ptr[s + 1]):
+            c = int(got[i, 0])
+            if c not in first:
+                first[c] = i
+                acc[c] = 0.0 + got[i, 1:].copy()
+            else:
+                acc[c] = acc[c] + got[i, 1:]
+    for c, i in first.items():
+        out[i, 0] = c
+        out[i, 1:-1] = V[c] - lr * acc[c][:-1]
+        out[i, -1] = w[c] - lr * acc[c][-1]
+    return out
+
+
+def _rows_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    from relevance_factorizationmachine_amd.dist import RowExchange, RowExchangeStep, owner_ranges
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        train, _ = synth.make_log("coat", "FM", "IPS", seed=0)
+        X, y, p = train["features"], train["labels"], train["pscores"]
+        n = X.shape[1]
+        w0, w, V = cpu_ref.fm_init(12345, n, K)
+        ids = np.stack([cpu_ref.batch_ids(X.shape[0], BATCH, e) for e in range(N_EPOCHS)])
+        lo_cols = owner_ranges(n, world)
+        sent = []
+
+        def grad_rows_fn(lo, hi, it):
+            rec, bounds, g_w0 = _np_grad_rows(X, y, p, w0, w, V, ids[it, lo:hi], lo_cols, world)
+            sent.append(len(rec))
+            return torch.from_numpy(rec), torch.from_numpy(np.concatenate([bounds, [g_w0]]))
+
+        def reduce_fn(got, seg_ptr):
+            return torch.from_numpy(_np_reduce_rows(got.numpy(), seg_ptr, w, V, LR))
+
+        def set_rows_fn(everything, gw0_parts):
+            e = everything.numpy()
+            live = e[e[:, 0] >= 0]
+            cols = live[:, 0].astype(np.int64)
+            assert len(np.unique(cols)) == len(cols)  # every column has exactly one owner row
+            V[cols] = live[:, 1:-1]
+            w[cols] = live[:, -1]
+            s = 0.0
+            for g in gw0_parts:
+                s += g
+            w0[...] -= LR * s
+
+        comm = RowExchange.for_torch(dist, world, rank, n, K, backend="gloo")
+        step = RowExchangeStep(world, rank, comm, grad_rows_fn, reduce_fn, set_rows_fn)
+        for it in range(N_EPOCHS):
+            step.step(it, BATCH)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), w0=w0, w=w, V=V, sent=np.array(sent))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_touched_row_exchange_equals_single_process(tmp_path, world):
+    import torch.multiprocessing as mp
+
+    from relevance_factorizationmachine_amd.dist import shard_bounds as sb
+
+    mp.spawn(_rows_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    train, val = synth.make_log("coat", "FM", "IPS", seed=0)
+    X, y, p = train["features"], train["labels"], train["pscores"]
+    n = X.shape[1]
+    ref = cpu_ref.fm_fit(train, val, n_epochs=N_EPOCHS, n_factors=K, lr=LR, batch_size=BATCH,
+                         seed=12345, with_losses=False)
+    outs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for o in outs:
+        assert np.max(np.abs(o["V"] - ref["V"])) < 1e-12
+        assert np.max(np.abs(o["w"] - ref["w"])) < 1e-12
+        assert np.max(np.abs(o["w0"] - ref["w0"])) < 1e-12
+    for o in outs[1:]:  # replicas bitwise identical: every row computed once, by its owner
+        np.testing.assert_array_equal(outs[0]["V"], o["V"])
+        np.testing.assert_array_equal(outs[0]["w"], o["w"])
+        np.testing.assert_array_equal(outs[0]["w0"], o["w0"])
+    # bit for bit the single-process oracle whose step adds the shards' gradients in rank order
+    w0, w, V = cpu_ref.fm_init(12345, n, K)
+    ids = np.stack([cpu_ref.batch_ids(X.shape[0], BATCH, e) for e in range(N_EPOCHS)])
+    for it in range(N_EPOCHS):
+        gV, gw, g0 = np.zeros_like(V), np.zeros_like(w), 0.0
+        seen_V = np.zeros(n, dtype=bool)
+        for r in range(world):
+            lo, hi = sb(BATCH, world, r)
+            rows = ids[it, lo:hi]
+            _, a0, aw, aV = cpu_ref.fm_gradients(X[rows], y[rows], p[rows], w0, w, V)
+            cols = np.unique(X[rows].indices)
+            fresh = cols[~seen_V[cols]]
+            again = cols[seen_V[cols]]
+            gV[fresh], gw[fresh] = aV[fresh], aw[fresh]
+            gV[again] += aV[again]
+            gw[again] += aw[again]
+            seen_V[cols] = True
+            g0 += a0
+        t = np.flatnonzero(seen_V)
+        V[t] = V[t] - LR * gV[t]
+        w[t] = w[t] - LR * gw[t]
+        w0 -= LR * g0
+    np.testing.assert_array_equal(outs[0]["V"], V)
+    np.testing.assert_array_equal(outs[0]["w"], w)
+    np.testing.assert_array_equal(outs[0]["w0"], w0)
+    # only touched rows travel: far fewer records than columns x iterations would be
+    assert all(int(o["sent"].max()) <= n for o in outs)

@@ -755,11 +755,17 @@ int32_t rfm_fm_grad_rows(rfm_ctx* ctx, rfm_fm_plan* plan, const int32_t* d_row_i
     int32_t* chunk = plan->chunk_cnt.as<int32_t>();
     hipLaunchKernelGGL(touch_count_kernel, dim3(n_chunks), dim3(kBlock), 0, ctx->stream, touch, id,
                        n, chunk);
-    hipLaunchKernelGGL(touch_scan_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, touch, id, n,
-                       chunk, n_chunks, d_n_rows, n_ranges ? d_range_lo : nullptr, int(n_ranges),
-                       d_range_bounds);
-    hipLaunchKernelGGL(touch_gather_kernel, dim3(n_chunks), dim3(kBlock), 0, ctx->stream, touch,
-                       id, n, k, chunk, table, d_rows, cap_rows, d_gw0);
+    hipLaunchKernelGGL(touch_list_kernel, dim3(n_chunks), dim3(kBlock), 0, ctx->stream, touch, id,
+                       n, k, chunk, n_chunks, table, d_rows, cap_rows, d_n_rows, d_gw0,
+                       n_ranges ? d_range_lo : nullptr, int(n_ranges), d_range_bounds);
+    {
+      const int wpb = kBlock / kWave;
+      const int64_t most = std::min<int64_t>(cap_rows, n);
+      const int grid = int(std::max<int64_t>(
+          1, std::min<int64_t>((most + wpb - 1) / wpb, int64_t(ctx->n_cu) * 8)));
+      hipLaunchKernelGGL(rows_fill_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, table, d_rows,
+                         d_n_rows, cap_rows, n, k);
+    }
     RFM_HIP_CHECK(hipGetLastError());
   });
 }

@@ -47,99 +47,80 @@ __global__ __launch_bounds__(kBlock) void touch_count_kernel(const int32_t* touc
   if (threadIdx.x == 0) chunk_cnt[blockIdx.x] = s;
 }
 
-// one workgroup: exclusive scan of the chunk counts (in place: chunk_cnt[b] becomes the
-// position of chunk b's first record), the total, and for every range start range_lo[i]
-// the number of stamped columns below it (= position of the range's first record).
-__global__ __launch_bounds__(kBlock) void touch_scan_kernel(const int32_t* touch, int32_t id,
-                                                           int64_t n, int32_t* chunk_cnt,
-                                                           int n_chunks, int32_t* n_touched,
+// Chunk b's stamped columns, ascending, become the column fields of the records
+// chunk_off(b) .. : the workgroup adds up the counts of the chunks before it (a few
+// thousand ints at most), ranks its own stamped columns by ballots, and writes
+// rows[pos][0] = column.  The workgroup whose chunk holds a range start lo_i also owns
+// range_bounds[i] (= records with a column below lo_i); the last one writes the total.
+__global__ __launch_bounds__(kBlock) void touch_list_kernel(const int32_t* touch, int32_t id,
+                                                           int64_t n, int k,
+                                                           const int32_t* chunk_cnt, int n_chunks,
+                                                           const double* table, double* rows,
+                                                           int64_t cap_rows, int32_t* n_touched,
+                                                           double* out_gw0,
                                                            const int32_t* range_lo, int n_ranges,
                                                            int32_t* range_bounds) {
   __shared__ int lds[kBlock / kWave];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int b0 = 0; b0 < n_chunks; b0 += kBlock) {
-    const int b = b0 + threadIdx.x;
-    const int v = b < n_chunks ? chunk_cnt[b] : 0;
-    // inclusive scan inside the wave, then over the waves
-    int x = v;
-    for (int o = 1; o < kWave; o <<= 1) {
-      const int y = __shfl_up(x, o, kWave);
-      if (int(threadIdx.x % kWave) >= o) x += y;
-    }
-    __syncthreads();
-    if (threadIdx.x % kWave == kWave - 1) lds[threadIdx.x / kWave] = x;
-    __syncthreads();
-    int before = carry;
-    for (int w = 0; w < int(threadIdx.x / kWave); ++w) before += lds[w];
-    if (b < n_chunks) chunk_cnt[b] = before + x - v;
-    __syncthreads();
-    if (threadIdx.x == kBlock - 1) carry = before + x;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) n_touched[0] = carry;
-  // positions of the range starts: whole chunks below come from the scan, the rest is counted
-  for (int i = 0; i <= n_ranges && range_lo; ++i) {
-    const int64_t lo = i < n_ranges ? int64_t(range_lo[i]) : n;  // wave-uniform
-    const int64_t clamped = lo < 0 ? 0 : (lo > n ? n : lo);
-    const int b = int(clamped / kTouchChunk);
-    int cnt = 0;
-    for (int64_t c = int64_t(b) * kTouchChunk + threadIdx.x; c < clamped; c += kBlock)
-      cnt += touch[c] == id ? 1 : 0;
-    const int part = block_sum_int(cnt, lds);
-    if (threadIdx.x == 0) range_bounds[i] = (b < n_chunks ? chunk_cnt[b] : carry) + part;
-    __syncthreads();
-  }
-}
-
-// records of chunk b, ascending by column, at rows[chunk_off[b] ...]
-__global__ __launch_bounds__(kBlock) void touch_gather_kernel(const int32_t* touch, int32_t id,
-                                                             int64_t n, int k,
-                                                             const int32_t* chunk_off,
-                                                             const double* table, double* rows,
-                                                             int64_t cap_rows, double* out_gw0) {
-  __shared__ int32_t list[kTouchChunk];
   __shared__ int wave_cnt[kBlock / kWave];
-  __shared__ int m_sh;
-  const int64_t c0 = int64_t(blockIdx.x) * kTouchChunk;
+  const int b = blockIdx.x;
+  const int64_t c0 = int64_t(b) * kTouchChunk;
   const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
-  if (threadIdx.x == 0) m_sh = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && out_gw0) out_gw0[0] = table[n * k + n];
-  __syncthreads();
+  const int width = k + 2;
+  if (b == 0 && threadIdx.x == 0 && out_gw0) out_gw0[0] = table[n * k + n];
+  int part = 0;
+  for (int i = threadIdx.x; i < b; i += kBlock) part += chunk_cnt[i];
+  const int first = block_sum_int(part, lds);
+  int m = 0;
   for (int r0 = 0; r0 < kTouchChunk; r0 += kBlock) {
     const int64_t c = c0 + r0 + threadIdx.x;
     const bool on = c < n && touch[c] == id;
     const unsigned long long mask = __ballot(on);
+    __syncthreads();
     if (lane == 0) wave_cnt[wv] = __popcll(mask);
     __syncthreads();
-    int pos = m_sh;
-    for (int w = 0; w < wv; ++w) pos += wave_cnt[w];
-    pos += __popcll(mask & ((1ull << lane) - 1ull));
-    if (on) list[pos] = int32_t(c);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int t = 0;
-      for (int w = 0; w < kBlock / kWave; ++w) t += wave_cnt[w];
-      m_sh += t;
+    int pos = first + m;
+    int round = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) {
+      if (w < wv) pos += wave_cnt[w];
+      round += wave_cnt[w];
     }
-    __syncthreads();
+    pos += __popcll(mask & ((1ull << lane) - 1ull));
+    if (on && pos < cap_rows) rows[int64_t(pos) * width] = double(c);
+    m += round;
   }
-  const int m = m_sh;
+  if (b == n_chunks - 1 && threadIdx.x == 0) {
+    n_touched[0] = first + m;
+    if (range_lo) range_bounds[n_ranges] = first + m;
+  }
+  // owner-range starts that fall into this chunk (the last chunk also takes those at or past n)
+  for (int i = 0; range_lo && i < n_ranges; ++i) {
+    int64_t lo = range_lo[i];
+    lo = lo < 0 ? 0 : (lo > n ? n : lo);
+    const bool mine = (lo >= c0 && lo < c0 + kTouchChunk) || (b == n_chunks - 1 && lo >= c0);
+    if (!mine) continue;  // uniform over the workgroup
+    int cnt = 0;
+    for (int64_t c = c0 + threadIdx.x; c < lo; c += kBlock) cnt += touch[c] == id ? 1 : 0;
+    const int below = block_sum_int(cnt, lds);
+    if (threadIdx.x == 0) range_bounds[i] = first + below;
+  }
+}
+
+// fills the records whose column field touch_list_kernel wrote: one wave per record
+__global__ __launch_bounds__(kBlock) void rows_fill_kernel(const double* table, double* rows,
+                                                          const int32_t* n_rows, int64_t cap_rows,
+                                                          int64_t n, int k) {
+  const int lane = threadIdx.x % kWave;
+  const int64_t wave = int64_t(blockIdx.x) * (kBlock / kWave) + threadIdx.x / kWave;
+  const int64_t n_waves = int64_t(gridDim.x) * (kBlock / kWave);
+  int64_t cnt = n_rows[0];
+  if (cnt > cap_rows) cnt = cap_rows;
   const int width = k + 2;
-  const int64_t first = chunk_off[blockIdx.x];
-  for (int idx = threadIdx.x; idx < m * width; idx += kBlock) {
-    const int r = idx / width, f = idx - r * width;
-    const int64_t col = list[r];
-    if (first + r >= cap_rows) continue;  // the caller sees the true count and can tell
-    double v;
-    if (f == 0)
-      v = double(col);
-    else if (f <= k)
-      v = table[col * k + (f - 1)];
-    else
-      v = table[n * k + col];
-    rows[(first + r) * width + f] = v;
+  for (int64_t i = wave; i < cnt; i += n_waves) {
+    double* row = rows + i * width;
+    const int64_t col = int64_t(row[0]);
+    for (int f = lane; f < k; f += kWave) row[1 + f] = table[col * k + f];
+    if (lane == 0) row[k + 1] = table[n * k + col];
   }
 }
 

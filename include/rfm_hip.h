@@ -144,7 +144,16 @@ int32_t rfm_fm_plan_hot_columns(const rfm_fm_plan* plan, int32_t* h_out, int32_t
  * rows d_row_ids[0..batch): residual e = y/p - predict(old params); batch-SUM
  * gradients (no 1/|B|); w0, w, V updated in place with lr.  The CSR / label /
  * propensity arrays are the device copy of the log the plan was built from
- * (the step reads the plan's own records of it). */
+ * (the step reads the plan's own records of it).
+ * PRECONDITION of every call that takes the row ids of a step (rfm_fm_step,
+ * rfm_fm_grad, rfm_fm_grad_rows, rfm_fm_train, rfm_fm_train_dp): the ids of one
+ * step lie in 0 .. n_rows-1 of the plan's log and are DISTINCT -- what
+ * resample(replace=False) yields (src/fm.py:72-79).  A row's batch position is
+ * recorded with a plain store, so a repeated id would silently lose one of its
+ * contributions, and an id outside the log would index the records out of
+ * bounds.  The calls do not check this by default; with the environment
+ * variable RFM_CHECK_IDS=1 they validate the ids on the device first (this
+ * synchronises the stream) and return RFM_ERR_BAD_ARG. */
 int32_t rfm_fm_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
                     const int32_t* d_indices, const double* d_values, const double* d_y,
                     const double* d_pscore, const int32_t* d_row_ids, int64_t batch,

@@ -26,7 +26,11 @@ struct Rccl {
 const Rccl& rccl() {
   static Rccl api = [] {
     Rccl a;
-    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // an RCCL the process has already mapped (PyTorch's own, bound to PyTorch's HIP runtime)
+    // is the one to use: a second copy would bring a second runtime with it
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) rfm::fail(RFM_ERR_INTERNAL, "cannot load librccl.so: %s", dlerror());

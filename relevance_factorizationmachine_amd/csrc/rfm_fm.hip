@@ -187,6 +187,8 @@ struct rfm_fm_plan {
   // rows of the current step
   rfm::DevBuf row_table, touch, chunk_cnt;
   int32_t touch_seq = 0;
+  rfm::DevBuf ids_seen, ids_flags;  // RFM_CHECK_IDS=1: validation of the steps' row ids
+  int32_t ids_stamp = 0;
   size_t device_bytes() const {
     return ent.bytes + rows.bytes + slot_t.bytes + slots.bytes + win.bytes + cross.bytes +
            carry_idx.bytes + carries.bytes + Q.bytes + err.bytes + hot_cols.bytes +
@@ -215,6 +217,31 @@ void check_step_args(const rfm_fm_plan* plan, const void* indptr, const void* in
   RFM_REQUIRE(indptr && indices && values && y && p && ids, "null pointer");
   RFM_REQUIRE(batch >= 1 && batch <= plan->max_batch, "batch=%lld outside 1..max_batch=%lld",
               (long long)batch, (long long)plan->max_batch);
+}
+
+// RFM_CHECK_IDS=1 (debugging aid; synchronises): the ids of every one of the n_iters
+// batches must be rows of the plan's log and distinct within their batch
+void validate_ids(rfm_ctx* ctx, rfm_fm_plan* plan, const int32_t* d_ids, int64_t batch,
+                  int64_t n_iters) {
+  if (env_int("RFM_CHECK_IDS", 0) == 0 || batch <= 0 || n_iters <= 0) return;
+  if (!plan->ids_seen.p || plan->ids_stamp > INT32_MAX - n_iters - 2) {
+    plan->ids_seen.ensure(size_t(plan->n_rows) * 4);
+    plan->ids_flags.ensure(8);
+    RFM_HIP_CHECK(hipMemsetAsync(plan->ids_seen.p, 0, plan->ids_seen.bytes, ctx->stream));
+    plan->ids_stamp = 0;
+  }
+  RFM_HIP_CHECK(hipMemsetAsync(plan->ids_flags.p, 0, 8, ctx->stream));
+  const int64_t total = batch * n_iters;
+  const int grid = int(std::min<int64_t>((total + kBlock - 1) / kBlock, int64_t(ctx->n_cu) * 8));
+  hipLaunchKernelGGL(ids_check_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_ids, batch,
+                     n_iters, plan->n_rows, plan->ids_seen.as<int32_t>(), plan->ids_stamp + 1,
+                     plan->ids_flags.as<int32_t>());
+  plan->ids_stamp += int32_t(n_iters);
+  int32_t flags[2] = {0, 0};
+  RFM_HIP_CHECK(hipMemcpyAsync(flags, plan->ids_flags.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  RFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  RFM_REQUIRE(!flags[0], "a row id lies outside the plan's log (0..%lld)", (long long)plan->n_rows - 1);
+  RFM_REQUIRE(!flags[1], "a row id occurs twice in one batch: the ids of a step must be distinct");
 }
 
 // the three launches of one step; grad == nullptr -> update in place
@@ -680,6 +707,7 @@ int32_t rfm_fm_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   return guarded([&] {
     RFM_REQUIRE(ctx && d_w0 && d_w && d_V, "null pointer");
     check_step_args(plan, d_indptr, d_indices, d_values, d_y, d_pscore, d_row_ids, batch);
+    validate_ids(ctx, plan, d_row_ids, batch, 1);
     enqueue_step(ctx, plan, d_indptr, d_indices, d_values, d_y, d_pscore, d_row_ids, batch,
                  d_w0, d_w, d_V, lr, nullptr);
   });
@@ -692,6 +720,7 @@ int32_t rfm_fm_grad(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   return guarded([&] {
     RFM_REQUIRE(ctx && d_w0 && d_w && d_V && d_grad, "null pointer");
     check_step_args(plan, d_indptr, d_indices, d_values, d_y, d_pscore, d_row_ids, batch);
+    validate_ids(ctx, plan, d_row_ids, batch, 1);
     enqueue_step(ctx, plan, d_indptr, d_indices, d_values, d_y, d_pscore, d_row_ids, batch,
                  const_cast<double*>(d_w0), const_cast<double*>(d_w), const_cast<double*>(d_V),
                  0.0, d_grad);
@@ -744,6 +773,7 @@ int32_t rfm_fm_grad_rows(rfm_ctx* ctx, rfm_fm_plan* plan, const int32_t* d_row_i
     const int32_t id = ++plan->touch_seq;
     double* table = plan->row_table.as<double>();
     int32_t* touch = plan->touch.as<int32_t>();
+    validate_ids(ctx, plan, d_row_ids, batch, 1);
     if (batch > 0) {
       enqueue_step(ctx, plan, nullptr, nullptr, nullptr, nullptr, nullptr, d_row_ids, batch,
                    const_cast<double*>(d_w0), const_cast<double*>(d_w), const_cast<double*>(d_V),
@@ -834,6 +864,8 @@ int32_t rfm_fm_train_dp(rfm_ctx* ctx, rfm_fm_plan* plan, const int32_t* d_ids,
     RFM_REQUIRE(n_iters >= 0 && global_batch >= 1, "bad shape");
     RFM_REQUIRE(0 <= shard_lo && shard_lo <= shard_hi && shard_hi <= global_batch, "bad shard");
     RFM_REQUIRE(shard_hi - shard_lo <= plan->max_batch, "shard larger than the plan's max_batch");
+    for (int64_t it = 0; it < n_iters; ++it)
+      validate_ids(ctx, plan, d_ids + it * global_batch + shard_lo, shard_hi - shard_lo, 1);
     const int64_t count = plan->n_features * int64_t(plan->k + 1) + 1;
     const int64_t nk = plan->n_features * int64_t(plan->k);
     const int apply_grid =
@@ -870,6 +902,7 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
     RFM_REQUIRE(n_iters >= 0, "negative n_iters");
     if (n_iters == 0) return;
     check_step_args(plan, d_indptr, d_indices, d_values, d_y, d_pscore, d_ids, batch);
+    validate_ids(ctx, plan, d_ids, batch, n_iters);
     if (d_out_val_loss)
       RFM_REQUIRE(d_val_indptr && d_val_indices && d_val_values && d_val_y && d_val_pscore &&
                       n_val >= 1,

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 namespace rfm {
 
@@ -70,7 +71,8 @@ __device__ inline double block_sum(double v, double* lds) {
 }
 
 __device__ inline double sigmoid_clipped(double z) {
-  z = fmin(fmax(z, -kLogitClip), kLogitClip);
+  // np.clip keeps a NaN logit NaN (src/base.py:65); fmin/fmax alone would turn it into -700
+  z = z != z ? z : fmin(fmax(z, -kLogitClip), kLogitClip);
   return 1.0 / (1.0 + exp(-z));
 }
 
@@ -207,7 +209,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
   for (int64_t base = int64_t(blockIdx.x) * (GPB * R); base < a.n_rows;
        base += int64_t(gridDim.x) * (GPB * R)) {
     int64_t t[R], r[R];
-    int32_t p0[R];  // entry offsets fit 31 bits (checked when the plan / call is set up)
+    // entry offsets: the plan checks that they fit 31 bits; the caller's CSR is taken as it is
+    using EntryOff = typename std::conditional<REC, int32_t, int64_t>::type;
+    EntryOff p0[R];
     int len[R];
     double yy[R], pp[R];
     bool valid[R];
@@ -225,13 +229,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
     for (int i = 0; i < R; ++i) {
       if (REC) {
         const RowRec rec = a.rows[r[i]];
-        p0[i] = int32_t(rec.begin);
+        p0[i] = EntryOff(rec.begin);
         len[i] = valid[i] ? int(rec.len) : 0;
         yy[i] = rec.y;
         pp[i] = rec.p;
       } else {
         const int64_t b0 = a.indptr[r[i]], b1 = a.indptr[r[i] + 1];
-        p0[i] = int32_t(b0);
+        p0[i] = EntryOff(b0);
         len[i] = valid[i] ? int(b1 - b0) : 0;
         yy[i] = 0.0;
         pp[i] = 1.0;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
       for (int i = 0; i < R; ++i) {
         const int my = pb + l;
         // clamp into the row's own entries (entry 0 of the log for an empty row)
-        const int32_t at = len[i] > 0 ? p0[i] + min(my, len[i] - 1) : 0;
+        const EntryOff at = len[i] > 0 ? p0[i] + min(my, len[i] - 1) : 0;
         if (REC) {
           e[i] = a.ent[at];
         } else {
@@ -276,7 +280,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
           e[i].slot = 0;
           e[i].x = a.values[at];
         }
-        if (my >= len[i]) e[i] = Entry{0, 0, 0.0};
+        // padding: the row's own last entry again with x = 0 (not some fixed column: a
+        // non-finite row of V must reach only the rows that hold its column; an empty
+        // row, whose padding is entry 0 of the log, has its sums cleared below)
+        if (my >= len[i]) {
+          e[i].slot = 0;
+          e[i].x = 0.0;
+        }
       }
 #pragma unroll
       for (int i = 0; i < R; ++i) {
@@ -297,10 +307,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
 #pragma unroll
           for (int c = 0; c < NC; ++c) pv[i][c].load(vrow + fo[c]);
         }
-        // padding entries carry x = 0 and lanes past k get a zero multiplier: the
-        // products vanish without a select or branch, so the gathers above stay
-        // unconditional and in flight together (a non-finite V entry would turn
-        // such a product into NaN -- training has diverged by then anyway)
+        // padding entries carry x = 0 and lanes past k get a zero multiplier (both re-read
+        // values of a column the row holds anyway): the products vanish without a select
+        // or branch, so the gathers above stay unconditional and in flight together
 #pragma unroll
         for (int i = 0; i < R; ++i) {
 #pragma unroll
@@ -319,6 +328,14 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
 
 #pragma unroll
     for (int i = 0; i < R; ++i) {
+      if (len[i] == 0) {  // an empty row scores sigmoid(w0) whatever its padding gathered
+        s2[i] = 0.0;
+        lin[i] = 0.0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) q[i][c][v] = 0.0;
+      }
       double pair = -s2[i];
 #pragma unroll
       for (int c = 0; c < NC; ++c)
@@ -985,6 +1002,26 @@ __global__ __launch_bounds__(kBlock) void fm_finalize_kernel(FinArgs a, int nb_c
       a.grad[a.n * k + a.n] = -s;
     else
       a.w0[0] += a.lr * s;
+  }
+}
+
+// RFM_CHECK_IDS=1: the row ids of one step must lie in the log and be distinct (a row's
+// batch position is recorded with a plain store, so a repeated id would lose one of its
+// contributions).  seen[r] holds the stamp of the last iteration that named row r.
+__global__ __launch_bounds__(kBlock) void ids_check_kernel(const int32_t* ids, int64_t batch,
+                                                          int64_t n_iters, int64_t n_rows,
+                                                          int32_t* seen, int32_t stamp0,
+                                                          int32_t* flags) {
+  const int64_t total = batch * n_iters;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < total;
+       i += int64_t(gridDim.x) * kBlock) {
+    const int32_t r = ids[i];
+    const int32_t stamp = stamp0 + int32_t(i / batch);
+    if (r < 0 || r >= n_rows) {
+      atomicOr(&flags[0], 1);
+    } else if (atomicExch(&seen[r], stamp) == stamp) {
+      atomicOr(&flags[1], 1);
+    }
   }
 }
 

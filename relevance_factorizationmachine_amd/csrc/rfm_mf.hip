@@ -69,7 +69,7 @@ struct MfPack<2> {
 };
 
 __device__ inline double mf_sigmoid(double z) {
-  z = fmin(fmax(z, -kMfLogitClip), kMfLogitClip);
+  z = z != z ? z : fmin(fmax(z, -kMfLogitClip), kMfLogitClip);  // np.clip keeps NaN
   return 1.0 / (1.0 + exp(-z));
 }
 

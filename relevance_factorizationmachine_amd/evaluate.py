@@ -226,10 +226,39 @@ class EvalLoop:
         self._flush(n_done)
         return self.values
 
+    def leave_scores(self, epoch: int) -> None:
+        """The reference's ``evaluate`` stores the scores it was given in its frame
+        (``interaction_df["y_score"] = y_scores``, utils/evaluate.py:224): leave the last
+        iteration's there, as the last host callback would have."""
+        if epoch < 0:
+            return
+        try:
+            self.rt.sync()
+            self.evaluator.interaction_df["y_score"] = self.slot(epoch)[: self.frame.n_rows].cpu().numpy()
+        except Exception:  # noqa: BLE001 -- a read-only or exotic frame: nothing to leave
+            pass
 
-def recognise(evaluator, estimator: str):
-    """``(users, labels, pscores, k)`` of a ValEvaluator-like object, or ``None``
-    when it is something else (then the caller keeps the host callback)."""
+
+def known_implementation(evaluator) -> bool:
+    """True when ``evaluator.evaluate`` is known to be the reference's IPS-DCG@k: the class
+    that DEFINES ``evaluate`` is ``ValEvaluator`` of a module called ``evaluate``
+    (``utils/evaluate.py:160-207``; a subclass that overrides ``evaluate()`` is not), or the
+    object opts in with ``rfm_device_evaluator = True``."""
+    if getattr(evaluator, "rfm_device_evaluator", False) is True:
+        return True
+    for cls in type(evaluator).__mro__:
+        if "evaluate" in vars(cls):
+            return cls.__qualname__ == "ValEvaluator" and cls.__module__.split(".")[-1] == "evaluate"
+    return False
+
+
+def recognise(evaluator, estimator: str, any_implementation: bool = False):
+    """``(users, labels, pscores, k)`` of the reference's ValEvaluator (or an object that
+    opts in, see ``known_implementation``), or ``None`` when it is something else (then the
+    caller keeps the host callback).  ``any_implementation`` skips the check of whose
+    ``evaluate()`` it is and looks at the attributes only."""
+    if not any_implementation and not known_implementation(evaluator):
+        return None
     frame = getattr(evaluator, "interaction_df", None)
     k = getattr(evaluator, "k", None)
     if frame is None or not isinstance(k, (int, np.integer)) or k < 1:

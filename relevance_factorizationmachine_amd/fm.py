@@ -130,6 +130,10 @@ class FactorizationMachines(PointwiseBaseRecommender):
                       self.hot_min_count)
         tl = rt.empty((self.n_epochs,), y.dtype)
         vl = rt.empty((self.n_epochs,), y.dtype)
+        # an empty validation set: the reference's mean over no rows is nan (src/base.py:61)
+        has_val = va.shape[0] > 0
+        if not has_val:
+            vl.fill_(float("nan"))
 
         chunk = {"first": 0, "ids": None}
 
@@ -141,7 +145,7 @@ class FactorizationMachines(PointwiseBaseRecommender):
                 self.w0.dev.data_ptr(), self.w.dev.data_ptr(), self.V.dev.data_ptr(), float(self.lr),
                 va.indptr.data_ptr(), va.indices.data_ptr(), va.values.data_ptr(),
                 vy.data_ptr(), vp.data_ptr(), va.shape[0], LOSS_EPS,
-                tl.data_ptr() + first * 8, vl.data_ptr() + first * 8))
+                tl.data_ptr() + first * 8, vl.data_ptr() + first * 8 if has_val else None))
 
         try:
             frame = loop = ev = ev_X = None
@@ -182,6 +186,7 @@ class FactorizationMachines(PointwiseBaseRecommender):
                 self.val_metrics.extend(loop.finish(self.n_epochs))
                 self.evaluator_host_calls = loop.host_calls
                 self.evaluator_host_users = loop.host_users
+                loop.leave_scores(self.n_epochs - 1)
             rt.sync()
         finally:
             rt.sync()

@@ -108,6 +108,8 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
         vp = rt.upload(np.asarray(val["pscores"]), dtype=np.float64)
         tl = rt.empty((self.n_epochs,), y.dtype)
         vl = rt.empty((self.n_epochs,), y.dtype)
+        if va.n == 0:  # the reference's mean over no rows is nan (src/base.py:61)
+            vl.fill_(float("nan"))
         params = (self.P.dev.data_ptr(), self.Q.dev.data_ptr(), self.b_u.dev.data_ptr(),
                   self.b_i.dev.data_ptr())
         b = float(self.b)
@@ -151,9 +153,10 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
                 rt.ctx, tr.users.data_ptr(), tr.items.data_ptr(), y.data_ptr(), p.data_ptr(),
                 ids_ptr, self.batch_size, *params, b, self.n_factors, LOSS_EPS, None,
                 tl.data_ptr() + epoch * 8))
-            _lib.check(rt.lib.rfm_mf_predict_loss(
-                rt.ctx, va.users.data_ptr(), va.items.data_ptr(), vy.data_ptr(), vp.data_ptr(),
-                None, va.n, *params, b, self.n_factors, LOSS_EPS, None, vl.data_ptr() + epoch * 8))
+            if va.n > 0:
+                _lib.check(rt.lib.rfm_mf_predict_loss(
+                    rt.ctx, va.users.data_ptr(), va.items.data_ptr(), vy.data_ptr(), vp.data_ptr(),
+                    None, va.n, *params, b, self.n_factors, LOSS_EPS, None, vl.data_ptr() + epoch * 8))
             if ev_frame is not None:
                 _lib.check(rt.lib.rfm_mf_predict(
                     rt.ctx, ev_pairs.users.data_ptr(), ev_pairs.items.data_ptr(), None, ev_pairs.n,
@@ -171,6 +174,7 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
             self.val_metrics.extend(ev_loop.finish(self.n_epochs))
             self.evaluator_host_calls = ev_loop.host_calls
             self.evaluator_host_users = ev_loop.host_users
+            ev_loop.leave_scores(self.n_epochs - 1)
         return tl.cpu().numpy().tolist(), vl.cpu().numpy().tolist()
 
     def _epochs(self, id_stream: BatchIdStream):

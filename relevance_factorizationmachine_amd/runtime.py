@@ -107,8 +107,22 @@ class CsrCache:
         self.capacity = capacity
         self._items = []  # (weakref, key, DeviceCSR)
 
+    @staticmethod
+    def _fingerprint(X) -> tuple:
+        """Cheap content check: shape, nnz and a sample of the three CSR arrays (ends and a
+        stride through the middle), so that a matrix edited in place between two calls is
+        uploaded again instead of being scored from the stale device copy."""
+        nnz = int(X.nnz)
+        parts = [X.shape, nnz]
+        for arr in (getattr(X, "data", None), getattr(X, "indices", None), getattr(X, "indptr", None)):
+            if arr is None or not len(arr):
+                continue
+            step = max(1, len(arr) // 1024)
+            parts.append(hash(np.concatenate([arr[:64], arr[::step], arr[-64:]]).tobytes()))
+        return tuple(parts)
+
     def get(self, X) -> DeviceCSR:
-        key = (id(X), X.shape, int(X.nnz))
+        key = (id(X),) + self._fingerprint(X)
         for ref, k, dev in self._items:
             if k == key and ref() is X:
                 return dev

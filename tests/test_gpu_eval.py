@@ -176,6 +176,7 @@ class _ValEvaluatorLike:
     with the oracle's restatement as its evaluate()."""
 
     metric_name = "DCG"
+    rfm_device_evaluator = True  # opts in: its evaluate() IS the reference's metric
 
     def __init__(self, frame, features, k=5, as_pandas=False):
         self.k = k
@@ -322,19 +323,25 @@ def test_unrecognised_evaluators_stay_host_callbacks(ev):
     frame = {"user": np.arange(4), "label": np.ones(4), "pscore": np.ones(4), "ones_pscore": np.ones(4)}
 
     class Other:
-        k, metric_name, interaction_df = 5, "Recall", frame
+        k, metric_name, interaction_df, rfm_device_evaluator = 5, "Recall", frame, True
 
     class NoFrame:
-        k, metric_name = 5, "DCG"
+        k, metric_name, rfm_device_evaluator = 5, "DCG", True
 
     class Short:
-        k, metric_name, interaction_df = 5, "DCG", {"user": np.arange(4)}
+        k, metric_name, interaction_df, rfm_device_evaluator = 5, "DCG", {"user": np.arange(4)}, True
 
-    for obj in (Other(), NoFrame(), Short(), object()):
+    class Unknown:  # the right attributes, but an evaluate() nobody vouches for
+        k, metric_name, interaction_df = 5, "DCG", frame
+
+        def evaluate(self, y_scores, estimator):
+            return 0.0
+
+    for obj in (Other(), NoFrame(), Short(), Unknown(), object()):
         assert evaluate.device_frame(rt, obj, "IPS", 4) is None
 
     class Good:
-        k, metric_name, interaction_df = 5, "DCG", frame
+        k, metric_name, interaction_df, rfm_device_evaluator = 5, "DCG", frame, True
 
     assert evaluate.device_frame(rt, Good(), "IPS", 4) is not None
     assert evaluate.device_frame(rt, Good(), "IPS", 5) is None  # scores would not match the frame

@@ -164,6 +164,7 @@ def test_evaluator_grouping_and_recognition():
 
     class Val:
         k, metric_name, interaction_df = 5, "DCG", frame
+        rfm_device_evaluator = True
 
     u, y, p, k = evaluate.recognise(Val(), "IPS")
     assert k == 5 and p[0] == 0.5 and u.shape == (1000,) and y.sum() == (users % 2).sum()
@@ -171,6 +172,47 @@ def test_evaluator_grouping_and_recognition():
     Val.metric_name = "Recall"
     assert evaluate.recognise(Val(), "IPS") is None
     assert evaluate.recognise(object(), "IPS") is None
+    # whose evaluate() is it?  Only the reference's own (class ValEvaluator of a module
+    # called evaluate), or an object that opts in, takes the device path: a subclass that
+    # overrides evaluate() keeps its host callback
+    import types
+    mod = types.ModuleType("utils.evaluate")
+    exec("class ValEvaluator:\n    k = 5\n    metric_name = 'DCG'\n"
+         "    def evaluate(self, y_scores, estimator):\n        return 0.0\n", mod.__dict__)
+    ref_like = mod.ValEvaluator()
+    ref_like.interaction_df = frame
+    assert evaluate.known_implementation(ref_like) and evaluate.recognise(ref_like, "IPS") is not None
+
+    class Custom(mod.ValEvaluator):
+        def evaluate(self, y_scores, estimator):
+            return 1.0
+
+    sub = Custom()
+    sub.interaction_df = frame
+    assert not evaluate.known_implementation(sub) and evaluate.recognise(sub, "IPS") is None
+    assert evaluate.recognise(sub, "IPS", any_implementation=True) is not None
+
+    class Inherits(mod.ValEvaluator):
+        pass
+
+    inh = Inherits()
+    inh.interaction_df = frame
+    assert evaluate.recognise(inh, "IPS") is not None
+
+
+def test_csr_cache_fingerprint_follows_in_place_edits():
+    from scipy.sparse import random as sprandom
+
+    from relevance_factorizationmachine_amd.runtime import CsrCache
+
+    X = sprandom(500, 40, density=0.1, format="csr", random_state=np.random.default_rng(0))
+    a = CsrCache._fingerprint(X)
+    assert a == CsrCache._fingerprint(X)
+    X.data[0] += 1.0
+    assert a != CsrCache._fingerprint(X)
+    b = CsrCache._fingerprint(X)
+    X.indices[-1] = (X.indices[-1] + 1) % 40
+    assert b != CsrCache._fingerprint(X)
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/utils"), reason="the reference tree is only in the build container")

@@ -118,8 +118,14 @@ int32_t rfm_fm_forward_loss(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t
 /* ---- FM: training plan --------------------------------------------------
  * One-time (per fit) device layout of the training log (train["features"],
  * ["labels"], ["pscores"] of src/fm.py:55-79) for the gradient without global
- * atomics: row records, entry records and a column-major view, built on the
- * host from the caller's HOST arrays and stored in plan-owned device memory.
+ * atomics: row records, entry records and a column-major view (entries sorted
+ * by column, row order kept inside a column), built ON THE DEVICE and stored in
+ * plan-owned device memory.  rfm_fm_plan_create takes the caller's HOST arrays
+ * (and uploads a transient copy); rfm_fm_plan_create_device takes the DEVICE copy
+ * of the log the caller already holds (same dtypes as everywhere: indptr int64,
+ * indices int32, values / labels / propensities float64).  Both reject an indptr
+ * that is not monotone, a column index outside 0..n_features-1 and a row that
+ * names a column twice (RFM_ERR_BAD_ARG).
  * max_batch bounds the batch size of later steps.  hot_min_count: a column
  * whose expected number of entries per batch (its training frequency *
  * max_batch / n_rows) reaches this value is accumulated on chip by the forward
@@ -129,6 +135,11 @@ int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t*
                            const double* h_values, const double* h_y, const double* h_pscore,
                            int64_t n_rows, int64_t n_features, int32_t n_factors,
                            int64_t max_batch, int32_t hot_min_count, rfm_fm_plan** out);
+int32_t rfm_fm_plan_create_device(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_indices,
+                                  const double* d_values, const double* d_y,
+                                  const double* d_pscore, int64_t n_rows, int64_t n_features,
+                                  int32_t n_factors, int64_t max_batch, int32_t hot_min_count,
+                                  rfm_fm_plan** out);
 int32_t rfm_fm_plan_destroy(rfm_fm_plan* plan);
 /* h_out8[0]=slot windows, [1]=columns crossing a window border, [2]=hot
  * columns, [3]=nnz, [4]=device bytes owned by the plan, [5]=forward workgroups

@@ -17,9 +17,10 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 # RFM_LIB_PATH: load another build of the same ABI (timing experiments under profiles/)
 LIB_PATH = os.environ.get("RFM_LIB_PATH") or os.path.join(PKG_DIR, "librfm_hip.so")
-SOURCES = ["rfm_capi.hip", "rfm_fm.hip", "rfm_mf.hip", "rfm_eval.hip", "rfm_host.cpp", "rfm_comm.cpp"]
+SOURCES = ["rfm_capi.hip", "rfm_fm.hip", "rfm_fm_plan.hip", "rfm_mf.hip", "rfm_eval.hip", "rfm_host.cpp", "rfm_comm.cpp"]
 HEADERS = [os.path.join(CSRC, "rfm_common.h"), os.path.join(CSRC, "rfm_fm_kernels.hpp"),
-           os.path.join(CSRC, "rfm_fm_rows.hpp"),
+           os.path.join(CSRC, "rfm_fm_rows.hpp"), os.path.join(CSRC, "rfm_fm_plan.h"),
+           os.path.join(CSRC, "rfm_fm_records.h"),
            os.path.join(os.path.dirname(PKG_DIR), "include", "rfm_hip.h")]
 
 RFM_OK, RFM_ERR_BAD_ARG, RFM_ERR_HIP, RFM_ERR_NO_DEVICE, RFM_ERR_INTERNAL = range(5)
@@ -84,6 +85,7 @@ SIGNATURES = {
     "rfm_fm_forward_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32,
                             _f64, _vp, _vp],
     "rfm_fm_plan_create": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _i32, C.POINTER(_vp)],
+    "rfm_fm_plan_create_device": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _i32, C.POINTER(_vp)],
     "rfm_fm_plan_destroy": [_vp],
     "rfm_fm_plan_info": [_vp, _vp],
     "rfm_fm_plan_hot_columns": [_vp, _vp, _i32],

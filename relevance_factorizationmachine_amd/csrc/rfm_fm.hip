@@ -51,20 +51,12 @@
 
 #include "rfm_common.h"
 #include "rfm_fm_kernels.hpp"
+#include "rfm_fm_plan.h"
 #include "rfm_fm_rows.hpp"
 
 static_assert(RFM_MAX_FACTORS <= 1024, "fm_finalize_kernel's LDS totals hold 1024+2 values");
 
 namespace rfm {
-
-// bytes of LDS a forward workgroup spends on the hot class sums (next to 8 KiB of
-// reduction scratch and the 33 KiB entry buffer of the 1024-thread shape: gfx950 gives a
-// workgroup up to 160 KiB)
-constexpr size_t kHotLdsBudget = 56 << 10;
-constexpr int kMaxHot = 160;  // beyond this the slab traffic outweighs what the class saves
-
-// slots per window of fm_consume_kernel for a lane-group width (WinShape<LPR>::WIN)
-inline int window_slots(int lpr) { return lpr >= 64 ? 64 : (lpr == 32 ? 64 : 4 * lpr); }
 
 // forward launch geometry: 1024-thread workgroups whose lane groups keep several
 // rows in flight once the batch fills the chip with them (one per CU: as few
@@ -74,18 +66,14 @@ struct FwdGeom {
   int block, grid;
 };
 
-inline int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
-
 inline FwdGeom forward_geom(const rfm_ctx* ctx, int64_t n_rows, const Shape& s, bool records) {
   static const int per_cu = std::max(1, env_int("RFM_FWD_PER_CU", kBigBlock >= 1024 ? 1 : 2));
   static const int force = env_int("RFM_FWD_BLOCK", 0);
   FwdGeom g;
   const int64_t rows_big = int64_t(kBigBlock / s.lpr) * rows_in_flight(s.nc);
   const int64_t blocks_big = (n_rows + rows_big - 1) / rows_big;
-  if (records && force != 256 && (force == 512 || blocks_big >= int64_t(ctx->n_cu) * per_cu)) {
+  (void)records;  // the caller's CSR arrays (predict, validation loss) take the same shapes
+  if (force != 256 && (force == 512 || blocks_big >= int64_t(ctx->n_cu) * per_cu)) {
     g.block = kBigBlock;
     g.grid = int(std::max<int64_t>(1, std::min<int64_t>(blocks_big, int64_t(ctx->n_cu) * per_cu)));
   } else {
@@ -98,7 +86,9 @@ inline FwdGeom forward_geom(const rfm_ctx* ctx, int64_t n_rows, const Shape& s, 
   return g;
 }
 
-constexpr int kMaxFwdGrid = 2048;  // upper bound of forward_geom().grid, sizes scratch
+int forward_grid(const rfm_ctx* ctx, int64_t rows, int n_factors) {
+  return forward_geom(ctx, rows, shape_for(n_factors), true).grid;
+}
 
 inline size_t forward_lds_bytes(int block, int lpr, int rows, int n_hot, int k) {
   return size_t(block) * 8 + (size_t(block) * rows + size_t(block / lpr)) * sizeof(Entry) +
@@ -126,6 +116,9 @@ void launch_forward(rfm_ctx* ctx, FwdArgs a, FwdGeom geom) {
       hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), true>),   \
                          dim3(geom.grid), dim3(kBigBlock), lds, ctx->stream, a);              \
     }                                                                                         \
+    else if (geom.block == kBigBlock)                                                         \
+      hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), false>),  \
+                         dim3(geom.grid), dim3(kBigBlock), lds, ctx->stream, a);              \
     else if (a.ent)                                                                           \
       hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, 256, 1, true>), dim3(geom.grid),        \
                          dim3(256), lds, ctx->stream, a);                                     \
@@ -168,45 +161,9 @@ int forward_loss_deferred(rfm_ctx* ctx, FwdArgs a, double* partial_row) {
 
 }  // namespace rfm
 
-// ---------------------------------------------------------------------------
-// training plan
-// ---------------------------------------------------------------------------
-struct rfm_fm_plan {
-  int32_t device = 0;
-  int64_t n_rows = 0, n_features = 0, nnz = 0, n_slots = 0, max_batch = 0;
-  int32_t k = 0;
-  int32_t n_win = 0, n_cross_short = 0, n_cross_long = 0, n_hot = 0;
-  int64_t step = 0;  // stamps the carries of a step
-  int32_t fwd_grid_max = 0;  // forward workgroups of a max_batch step (= hot-sum slabs)
-  rfm::DevBuf ent, rows, slot_t, slots, win, cross, carry_idx, carries, Q, err, hot_cols,
-      hot_slab, hot_part, err_partial;
-  rfm::DevBuf loss_rows;  // rfm_fm_train: per-workgroup loss partials of a run of iterations
-  std::vector<int32_t> h_hot_cols;  // host copy of hot_cols (rfm_fm_plan_hot_columns)
-  // touched-row gradients (rfm_fm_grad_rows), allocated on first use: the gradient table
-  // [G_V | g_w | g_w0] indexed by column, never cleared; touch[col] == touch_seq marks the
-  // rows of the current step
-  rfm::DevBuf row_table, touch, chunk_cnt;
-  int32_t touch_seq = 0;
-  rfm::DevBuf ids_seen, ids_flags;  // RFM_CHECK_IDS=1: validation of the steps' row ids
-  int32_t ids_stamp = 0;
-  size_t device_bytes() const {
-    return ent.bytes + rows.bytes + slot_t.bytes + slots.bytes + win.bytes + cross.bytes +
-           carry_idx.bytes + carries.bytes + Q.bytes + err.bytes + hot_cols.bytes +
-           hot_slab.bytes + hot_part.bytes + err_partial.bytes;
-  }
-};
-
 using namespace rfm;
 
 namespace {
-
-constexpr int32_t kDefaultHotMinCount = 32;
-constexpr int32_t kShortCross = 8;  // crossing columns up to this many carry rows: one lane group
-
-void upload(DevBuf& dst, const void* src, size_t bytes, hipStream_t stream) {
-  dst.alloc(bytes);
-  if (bytes) RFM_HIP_CHECK(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, stream));
-}
 
 void check_step_args(const rfm_fm_plan* plan, const void* indptr, const void* indices,
                      const void* values, const void* y, const void* p, const void* ids,
@@ -436,267 +393,6 @@ int32_t rfm_fm_forward_loss(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t
     f.eps = eps;
     f.out_pred = d_out_pred;
     forward_loss(ctx, f, d_out_loss);
-  });
-}
-
-int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t* h_indices,
-                           const double* h_values, const double* h_y, const double* h_pscore,
-                           int64_t n_rows, int64_t n_features, int32_t n_factors,
-                           int64_t max_batch, int32_t hot_min_count, rfm_fm_plan** out) {
-  return guarded([&] {
-    RFM_REQUIRE(ctx && h_indptr && h_y && h_pscore && out, "null pointer");
-    RFM_REQUIRE(n_rows >= 1 && n_features >= 1 && max_batch >= 1, "bad shape");
-    (void)shape_for(n_factors);
-    const int64_t nnz = h_indptr[n_rows];
-    RFM_REQUIRE(nnz >= 0 && nnz < (int64_t(1) << 31) - kWave, "nnz=%lld unsupported",
-                (long long)nnz);
-    RFM_REQUIRE(nnz == 0 || (h_indices && h_values), "null CSR arrays");
-    RFM_REQUIRE(n_features < (int64_t(1) << 31), "n_features too large");
-    const size_t nz = static_cast<size_t>(nnz);
-    const size_t nf = static_cast<size_t>(n_features);
-    const size_t nr = static_cast<size_t>(n_rows);
-
-    const bool timing = env_int("RFM_PLAN_TIMING", 0) != 0;
-    auto t_prev = std::chrono::steady_clock::now();
-    const auto lap = [&](const char* what) {
-      if (!timing) return;
-      const auto now = std::chrono::steady_clock::now();
-      fprintf(stderr, "[plan] %s: %.1f ms\n", what,
-              std::chrono::duration<double, std::milli>(now - t_prev).count());
-      t_prev = now;
-    };
-    // Host threads of the two passes over the CSR: rows are cut into contiguous ranges,
-    // every thread counts its range's entries per column, and the prefix of those counts
-    // over the threads gives each thread its own first slot in every column (row order
-    // inside a column is kept).  The per-thread tables are n_features ints each.
-    const int hw = int(std::thread::hardware_concurrency());
-    int n_thr = std::max(1, std::min({env_int("RFM_PLAN_THREADS", 16), hw > 0 ? hw : 1,
-                                      int(std::max<int64_t>(1, (int64_t(64) << 20) / n_features)),
-                                      int(std::max<int64_t>(1, nnz / 200000))}));
-    const auto row_lo = [&](int t) { return n_rows * t / n_thr; };
-    std::vector<std::string> thr_err(static_cast<size_t>(n_thr));
-    const auto run_threads = [&](auto&& body) {
-      if (n_thr == 1) {
-        body(0);
-      } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < n_thr; ++t) pool.emplace_back([&, t] { body(t); });
-        for (auto& th : pool) th.join();
-      }
-      for (const std::string& e : thr_err)
-        if (!e.empty()) fail(RFM_ERR_BAD_ARG, "%s", e.c_str());
-    };
-    const auto thread_fail = [&](int t, const char* fmt, long long a, long long b) {
-      char buf[256];
-      snprintf(buf, sizeof(buf), fmt, a, b);
-      if (thr_err[size_t(t)].empty()) thr_err[size_t(t)] = buf;
-    };
-
-    // column lengths; a row must not name a column twice (SciPy sums such duplicates
-    // before squaring -- the caller canonicalises, as the Python mirror does)
-    std::vector<std::vector<int32_t>> cnt_tc(static_cast<size_t>(n_thr));  // [thread][column]
-    run_threads([&](int t) {
-      std::vector<int32_t>& cnt = cnt_tc[size_t(t)];
-      cnt.assign(nf, 0);
-      std::vector<int64_t> seen_in_row(nf, -1);
-      for (int64_t r = row_lo(t); r < row_lo(t + 1); ++r) {
-        const int64_t b = h_indptr[r], e = h_indptr[r + 1];
-        if (b < 0 || e < b || e > nnz) {
-          thread_fail(t, "indptr not monotone / out of range at row %lld (nnz %lld)", (long long)r,
-                      (long long)nnz);
-          return;
-        }
-        for (int64_t p = b; p < e; ++p) {
-          const int32_t c = h_indices[p];
-          if (c < 0 || c >= n_features) {
-            thread_fail(t, "column index %lld out of range (row %lld)", (long long)c, (long long)r);
-            return;
-          }
-          if (seen_in_row[size_t(c)] == r) {
-            thread_fail(t, "row %lld names column %lld twice: sum duplicate entries first",
-                        (long long)r, (long long)c);
-            return;
-          }
-          seen_in_row[size_t(c)] = r;
-          cnt[size_t(c)]++;
-        }
-      }
-    });
-    std::vector<int64_t> len(nf, 0);
-    for (int t = 0; t < n_thr; ++t)
-      for (size_t c = 0; c < nf; ++c) len[c] += cnt_tc[size_t(t)][c];
-    lap("count pass");
-    // hot class: expected entries per batch >= hot_min, most frequent first, LDS budget
-    std::vector<int32_t> hot_cols;
-    std::vector<int32_t> hot_rank(nf, -1);
-    if (hot_min_count >= 0) {
-      const int64_t hot_min = hot_min_count > 0 ? hot_min_count : kDefaultHotMinCount;
-      for (int64_t c = 0; c < n_features; ++c)
-        if (len[size_t(c)] * max_batch >= hot_min * n_rows) hot_cols.push_back(int32_t(c));
-      std::stable_sort(hot_cols.begin(), hot_cols.end(),
-                       [&](int32_t x, int32_t y) { return len[size_t(x)] > len[size_t(y)]; });
-      const size_t per_col = size_t(n_factors + 2) * 8;
-      // RFM_HOT_LDS_KB overrides the LDS budget (tuning experiments only)
-      const size_t budget = size_t(env_int("RFM_HOT_LDS_KB", int(kHotLdsBudget >> 10))) << 10;
-      const size_t cap = std::min<size_t>(size_t(env_int("RFM_MAX_HOT", kMaxHot)), budget / per_col);
-      if (hot_cols.size() > cap) hot_cols.resize(cap);
-      std::sort(hot_cols.begin(), hot_cols.end());
-      for (size_t h = 0; h < hot_cols.size(); ++h) hot_rank[size_t(hot_cols[h])] = int32_t(h);
-    }
-    // column-major rank of every sparse-class entry (stable: row order inside a column)
-    std::vector<int64_t> cptr(nf + 1, 0);
-    for (size_t c = 0; c < nf; ++c) cptr[c + 1] = cptr[c] + (hot_rank[c] >= 0 ? 0 : len[c]);
-    const int64_t n_slots = cptr[nf];
-    const size_t ns = static_cast<size_t>(n_slots);
-    lap("classes");
-    // staging buffers, left uninitialised: the threads of the fill pass write every element
-    // (and so fault the pages in, in parallel); only the paddings are set here
-    std::unique_ptr<Entry[]> ent(new Entry[nz + 1]);  // +1: clamp target of empty logs
-    ent[nz] = Entry{0, 0, 0.0};
-    std::unique_ptr<RowRec[]> rows(new RowRec[nr]);
-    std::unique_ptr<SlotRec[]> slots(new SlotRec[ns + 256]);  // padded by one window
-    for (size_t i = ns; i < ns + 256; ++i) slots[i] = SlotRec{0.0, 0, 0};
-    {
-      // thread t's first slot of column c: the column's base plus what earlier threads hold
-      std::vector<std::vector<int64_t>> cur_tc(static_cast<size_t>(n_thr));
-      for (int t = 0; t < n_thr; ++t) cur_tc[size_t(t)].resize(nf);
-      for (size_t c = 0; c < nf; ++c) {
-        int64_t at = cptr[c];
-        for (int t = 0; t < n_thr; ++t) {
-          cur_tc[size_t(t)][c] = at;
-          at += cnt_tc[size_t(t)][c];
-        }
-      }
-      run_threads([&](int t) {
-        std::vector<int64_t>& cursor = cur_tc[size_t(t)];
-        for (int64_t r = row_lo(t); r < row_lo(t + 1); ++r) {
-          const int64_t b = h_indptr[r], e = h_indptr[r + 1];
-          rows[size_t(r)] = RowRec{b, e - b, h_y[r], h_pscore[r]};
-          for (int64_t p = b; p < e; ++p) {
-            const int32_t c = h_indices[p];
-            Entry en{c, 0, h_values[p]};
-            if (hot_rank[size_t(c)] >= 0) {
-              en.slot = -1 - hot_rank[size_t(c)];
-            } else {
-              const int64_t sl = cursor[size_t(c)]++;
-              en.slot = int32_t(sl);
-              slots[size_t(sl)] = SlotRec{h_values[p], c, 0};
-            }
-            ent[size_t(p)] = en;
-          }
-        }
-      });
-    }
-    lap("allocate + fill pass");
-    // fixed slot windows (one per lane group of fm_consume_kernel) and the columns
-    // that cross a window border, with the carry rows they collect in window order
-    const Shape shp = shape_for(n_factors);
-    const int64_t WIN = window_slots(shp.lpr);
-    const int64_t n_win = (n_slots + WIN - 1) / WIN;
-    RFM_REQUIRE(n_win * 2 < (int64_t(1) << 31), "too many slot windows");
-    std::vector<WinInfo> win(static_cast<size_t>(n_win) + 1, WinInfo{0, 0, 0, 0});
-    for (int64_t w = 0; w < n_win; ++w) {
-      const int64_t b0 = w * WIN, e0 = std::min(n_slots, b0 + WIN);
-      const int32_t fc = slots[size_t(b0)].col, lc = slots[size_t(e0 - 1)].col;
-      int32_t flags = 0;
-      if (cptr[size_t(fc)] < b0 || cptr[size_t(fc) + 1] > e0) flags |= 1;
-      if (lc != fc && cptr[size_t(lc) + 1] > e0) flags |= 2;
-      win[size_t(w)] = WinInfo{fc, lc, flags, 0};
-    }
-    std::vector<CrossCol> cross_short, cross_long;
-    std::vector<int32_t> carry_idx;
-    for (size_t c = 0; c < nf; ++c) {
-      const int64_t b0 = cptr[c], e0 = cptr[c + 1];
-      if (e0 <= b0) continue;
-      const int64_t wf = b0 / WIN, wl = (e0 - 1) / WIN;
-      if (wf == wl) continue;
-      CrossCol cc{int32_t(c), int32_t(carry_idx.size()), 0, 0};
-      for (int64_t w = wf; w <= wl; ++w) {
-        const int slot = slots[size_t(w * WIN)].col == int32_t(c) ? 0 : 1;
-        carry_idx.push_back(int32_t(w * 2 + slot));
-        cc.idx_count++;
-      }
-      (cc.idx_count <= kShortCross ? cross_short : cross_long).push_back(cc);
-    }
-    std::vector<CrossCol> cross(cross_short);
-    cross.insert(cross.end(), cross_long.begin(), cross_long.end());
-
-    lap("windows + crossing lists");
-    RFM_HIP_CHECK(hipSetDevice(ctx->device));
-    auto plan = std::make_unique<rfm_fm_plan>();
-    plan->device = ctx->device;
-    plan->n_rows = n_rows;
-    plan->n_features = n_features;
-    plan->nnz = nnz;
-    plan->n_slots = n_slots;
-    plan->max_batch = max_batch;
-    plan->k = n_factors;
-    plan->n_win = int32_t(n_win);
-    plan->n_cross_short = int32_t(cross_short.size());
-    plan->n_cross_long = int32_t(cross_long.size());
-    plan->n_hot = int32_t(hot_cols.size());
-    plan->h_hot_cols = hot_cols;
-    plan->fwd_grid_max = forward_geom(ctx, max_batch, shp, true).grid;
-    upload(plan->ent, ent.get(), (nz + 1) * sizeof(Entry), ctx->stream);
-    upload(plan->rows, rows.get(), nr * sizeof(RowRec), ctx->stream);
-    upload(plan->slots, slots.get(), (ns + 256) * sizeof(SlotRec), ctx->stream);
-    upload(plan->win, win.data(), win.size() * sizeof(WinInfo), ctx->stream);
-    upload(plan->cross, cross.data(), cross.size() * sizeof(CrossCol), ctx->stream);
-    upload(plan->carry_idx, carry_idx.data(), carry_idx.size() * 4, ctx->stream);
-    upload(plan->hot_cols, hot_cols.data(), hot_cols.size() * 4, ctx->stream);
-    plan->slot_t.alloc((ns + 256) * 4);
-    RFM_HIP_CHECK(hipMemsetAsync(plan->slot_t.p, 0xFF, plan->slot_t.bytes, ctx->stream));
-    // carry rows [n_win*2][k+3]; stamp 0 never matches a step id (they start at 1)
-    plan->carries.alloc(std::max<size_t>(size_t(n_win) * 2, 1) * size_t(n_factors + 3) * 8);
-    RFM_HIP_CHECK(hipMemsetAsync(plan->carries.p, 0, plan->carries.bytes, ctx->stream));
-    plan->hot_slab.alloc(size_t(kMaxFwdGrid) * std::max<size_t>(hot_cols.size(), 1) *
-                         size_t(n_factors + 2) * 8);
-    plan->hot_part.alloc(std::max<size_t>(hot_cols.size(), 1) * kHotParts * size_t(n_factors + 2) * 8);
-    plan->err_partial.alloc(size_t(kMaxFwdGrid) * 8);
-    plan->Q.alloc(size_t(max_batch) * size_t(n_factors) * 8);
-    plan->err.alloc(size_t(max_batch) * 8);
-    // host vectors die at scope exit: wait for the copies
-    RFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    lap("device allocations + uploads");
-    // giving 270 MB of touched pages back to the kernel takes tens of milliseconds: let a
-    // detached thread do it while the caller goes on
-    std::thread([e = std::move(ent), r = std::move(rows), sl = std::move(slots)]() mutable {
-      e.reset();
-      r.reset();
-      sl.reset();
-    }).detach();
-    lap("hand staging to the freeing thread");
-    *out = plan.release();
-  });
-}
-
-int32_t rfm_fm_plan_destroy(rfm_fm_plan* plan) {
-  return guarded([&] {
-    if (!plan) return;
-    (void)hipSetDevice(plan->device);
-    delete plan;
-  });
-}
-
-int32_t rfm_fm_plan_info(const rfm_fm_plan* plan, int64_t* h_out8) {
-  return guarded([&] {
-    RFM_REQUIRE(plan && h_out8, "null pointer");
-    h_out8[0] = plan->n_win;
-    h_out8[1] = plan->n_cross_short + plan->n_cross_long;
-    h_out8[2] = plan->n_hot;
-    h_out8[3] = plan->nnz;
-    h_out8[4] = int64_t(plan->device_bytes());
-    h_out8[5] = plan->fwd_grid_max;
-    h_out8[6] = plan->n_slots;
-    h_out8[7] = 0;
-  });
-}
-
-int32_t rfm_fm_plan_hot_columns(const rfm_fm_plan* plan, int32_t* h_out, int32_t capacity) {
-  return guarded([&] {
-    RFM_REQUIRE(plan && (h_out || capacity == 0), "null pointer");
-    RFM_REQUIRE(capacity >= plan->n_hot, "capacity %d < %d hot columns", capacity, plan->n_hot);
-    std::copy(plan->h_hot_cols.begin(), plan->h_hot_cols.end(), h_out);
   });
 }
 

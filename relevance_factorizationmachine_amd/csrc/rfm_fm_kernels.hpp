@@ -9,26 +9,11 @@
 #include <cstdint>
 #include <type_traits>
 
+#include "rfm_fm_records.h"
+
 namespace rfm {
 
-constexpr int kBlock = 256;
-constexpr int kWave = 64;
 constexpr double kLogitClip = 700.0;  // src/base.py:65
-
-// ---------------------------------------------------------------------------
-// records of the training plan (built once per fit on the host)
-// ---------------------------------------------------------------------------
-struct Entry {       // one CSR entry of the training log, 16 B
-  int32_t col;       // feature column
-  int32_t slot;      // >= 0: slot of the sparse class; < 0: hot column -1-slot
-  double x;          // feature value
-};
-struct RowRec {      // one row of the training log, 32 B
-  int64_t begin;     // first entry
-  int64_t len;       // number of entries
-  double y;          // label
-  double p;          // propensity (already raised to pow_used by the loader)
-};
 
 // ---------------------------------------------------------------------------
 // helpers
@@ -562,9 +547,6 @@ __device__ inline void ordered_carry_sum(const double* carries, const int32_t* i
   __syncthreads();
 }
 
-// slab ranges a hot column's reduction is cut into (one workgroup each)
-constexpr int kHotParts = 4;
-
 // Part `part` of hot column h: slabs [part*n/kHotParts, (part+1)*n/kHotParts) summed
 // in block order into hot_part[h][part][0..k+2).  Whole workgroup.
 __device__ inline void hot_part_block(int h, int part, const double* hot_slab, int n_slabs,
@@ -579,20 +561,6 @@ __device__ inline void hot_part_block(int h, int part, const double* hot_slab, i
 // ---------------------------------------------------------------------------
 // 2. sparse-class gradient + update: one fixed window of slots per lane group
 // ---------------------------------------------------------------------------
-struct SlotRec {  // one slot of the column-major view, 16 B
-  double x;       // feature value
-  int32_t col;    // feature column
-  int32_t pad;
-};
-
-struct WinInfo {      // static description of one slot window, 16 B
-  int32_t first_col;  // column of the window's first slot
-  int32_t last_col;   // column of its last slot
-  int32_t flags;      // bit0: first column is not wholly inside the window
-                      // bit1: last column (!= first) continues after the window
-  int32_t pad;
-};
-
 struct WinRec {  // a marked slot of the window being processed, parked in LDS, 24 B
   int32_t t;     // batch position of the slot's row
   int32_t col;   // feature column
@@ -849,13 +817,6 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
 // 3. columns that cross window borders (carries in window order), hot columns
 //    (slabs in block order) and w0
 // ---------------------------------------------------------------------------
-struct CrossCol {      // a sparse-class column spanning more than one window
-  int32_t col;
-  int32_t idx_begin;   // its carry rows: carry_idx[idx_begin .. +idx_count)
-  int32_t idx_count;
-  int32_t pad;
-};
-
 struct FinArgs {
   const CrossCol* cross;  // [n_cross_short | n_cross_long]
   int32_t n_cross_short;  // few carry rows: one lane group per column

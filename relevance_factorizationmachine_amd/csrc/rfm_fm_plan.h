@@ -1,0 +1,56 @@
+// The FM training plan: the one-time (per fit) device layout of a training log that the
+// step kernels read.  Built by rfm_fm_plan.hip (on the device), used by rfm_fm.hip.
+#pragma once
+
+#include <vector>
+
+#include "rfm_common.h"
+
+struct rfm_fm_plan {
+  int32_t device = 0;
+  int64_t n_rows = 0, n_features = 0, nnz = 0, n_slots = 0, max_batch = 0;
+  int32_t k = 0;
+  int32_t n_win = 0, n_cross_short = 0, n_cross_long = 0, n_hot = 0;
+  int64_t step = 0;  // stamps the carries of a step
+  int32_t fwd_grid_max = 0;  // forward workgroups of a max_batch step (= hot-sum slabs)
+  rfm::DevBuf ent, rows, slot_t, slots, win, cross, carry_idx, carries, Q, err, hot_cols,
+      hot_slab, hot_part, err_partial;
+  rfm::DevBuf loss_rows;  // rfm_fm_train: per-workgroup loss partials of a run of iterations
+  std::vector<int32_t> h_hot_cols;  // host copy of hot_cols (rfm_fm_plan_hot_columns)
+  // touched-row gradients (rfm_fm_grad_rows), allocated on first use: the gradient table
+  // [G_V | g_w | g_w0] indexed by column, never cleared; touch[col] == touch_seq marks the
+  // rows of the current step
+  rfm::DevBuf row_table, touch, chunk_cnt;
+  int32_t touch_seq = 0;
+  rfm::DevBuf ids_seen, ids_flags;  // RFM_CHECK_IDS=1: validation of the steps' row ids
+  int32_t ids_stamp = 0;
+  size_t device_bytes() const {
+    return ent.bytes + rows.bytes + slot_t.bytes + slots.bytes + win.bytes + cross.bytes +
+           carry_idx.bytes + carries.bytes + Q.bytes + err.bytes + hot_cols.bytes +
+           hot_slab.bytes + hot_part.bytes + err_partial.bytes;
+  }
+};
+
+namespace rfm {
+
+// bytes of LDS a forward workgroup spends on the hot class sums (next to 8 KiB of
+// reduction scratch and the 33 KiB entry buffer of the 1024-thread shape: gfx950 gives a
+// workgroup up to 160 KiB)
+constexpr size_t kHotLdsBudget = 56 << 10;
+constexpr int kMaxHot = 160;  // beyond this the slab traffic outweighs what the class saves
+constexpr int32_t kDefaultHotMinCount = 32;
+constexpr int32_t kShortCross = 8;  // crossing columns up to this many carry rows: one lane group
+constexpr int kMaxFwdGrid = 2048;   // upper bound of the forward's grid, sizes scratch
+
+// slots per window of fm_consume_kernel for a lane-group width (WinShape<LPR>::WIN)
+inline int window_slots(int lpr) { return lpr >= 64 ? 64 : (lpr == 32 ? 64 : 4 * lpr); }
+
+inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+// workgroups the training forward launches for `rows` batch rows (defined in rfm_fm.hip)
+int forward_grid(const rfm_ctx* ctx, int64_t rows, int n_factors);
+
+}  // namespace rfm

@@ -1,0 +1,372 @@
+// Builder of the FM training plan (rfm_fm_plan_create / _create_device): the one-time,
+// per-fit layout of the training log (train["features"], ["labels"], ["pscores"] of
+// src/fm.py:55-79) that the step kernels of rfm_fm_kernels.hpp read.
+//
+// Everything of size nnz happens on the device, from the device copy of the caller's CSR:
+//   1. plan_rows_kernel     one thread per row: RowRec {first entry, length, label,
+//                           propensity}; checks indptr / column ranges; row_of[entry]
+//   2. rocprim radix sort   entries by column (stable: CSR order, hence row order, is
+//                           kept inside a column) -- the column-major view
+//   3. plan_starts_kernel   first sorted position of every column; a column named twice
+//                           by one row shows up as two neighbours of the same row
+//   (host, O(n_features + windows): hot class, slot base of every sparse column, window
+//    descriptors, crossing-column lists -- the only part that comes back from the device
+//    is the n_features + 1 column starts)
+//   4. plan_scatter_kernel  Entry {column, slot | hot rank, value} in CSR order and
+//                           SlotRec {value, column} in slot order
+// The slot order inside a column is the row order, as in the host builder this replaces,
+// so the fixed-order sums of fm_consume_kernel are bit-identical to what they were.
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <cstring>
+#include <memory>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+#include "rfm_fm_plan.h"
+#include "rfm_fm_records.h"
+
+namespace rfm {
+namespace {
+
+constexpr int32_t kHotTag = INT32_MIN;  // colinfo: kHotTag + hot rank; else slot - sorted position
+
+// flags[0] indptr not monotone / out of range, [1] column index out of range,
+// [2] a row names a column twice
+__global__ __launch_bounds__(kBlock) void plan_rows_kernel(const int64_t* indptr,
+                                                          const int32_t* indices,
+                                                          const double* y, const double* p,
+                                                          int64_t n_rows, int64_t nnz, int64_t n,
+                                                          RowRec* rows, int32_t* row_of,
+                                                          int32_t* flags) {
+  for (int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x; r < n_rows;
+       r += int64_t(gridDim.x) * kBlock) {
+    const int64_t b = indptr[r], e = indptr[r + 1];
+    if (b < 0 || e < b || e > nnz) {
+      atomicOr(&flags[0], 1);
+      rows[r] = RowRec{0, 0, y[r], p[r]};
+      continue;
+    }
+    rows[r] = RowRec{b, e - b, y[r], p[r]};
+    for (int64_t q = b; q < e; ++q) {
+      const int32_t c = indices[q];
+      if (c < 0 || c >= n) atomicOr(&flags[1], 1);
+      row_of[q] = int32_t(r);
+    }
+  }
+}
+
+// cstart[c] = first sorted position whose column is >= c (cstart[n] = nnz)
+__global__ __launch_bounds__(kBlock) void plan_starts_kernel(const int32_t* key, const int32_t* pos,
+                                                            const int32_t* row_of, int64_t nnz,
+                                                            int64_t n, int32_t* cstart,
+                                                            int32_t* flags) {
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i <= nnz;
+       i += int64_t(gridDim.x) * kBlock) {
+    const int64_t prev = i == 0 ? -1 : int64_t(key[i - 1]);
+    const int64_t cur = i == nnz ? n : int64_t(key[i]);
+    for (int64_t c = prev + 1; c <= cur; ++c) cstart[c] = int32_t(i);
+    if (i > 0 && i < nnz && prev == cur && row_of[pos[i]] == row_of[pos[i - 1]])
+      atomicOr(&flags[2], 1);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void plan_scatter_kernel(const int32_t* key, const int32_t* pos,
+                                                             const double* values,
+                                                             const int32_t* colinfo, int64_t nnz,
+                                                             Entry* ent, SlotRec* slots) {
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nnz;
+       i += int64_t(gridDim.x) * kBlock) {
+    const int32_t c = key[i], q = pos[i];
+    const double x = values[q];
+    const int32_t info = colinfo[c];
+    if (info < kHotTag + (1 << 20)) {  // hot column: -1 - rank
+      ent[q] = Entry{c, -1 - (info - kHotTag), x};
+    } else {
+      const int32_t sl = int32_t(i + info);
+      ent[q] = Entry{c, sl, x};
+      slots[sl] = SlotRec{x, c, 0};
+    }
+  }
+}
+
+void upload(DevBuf& dst, const void* src, size_t bytes, hipStream_t stream) {
+  dst.alloc(bytes);
+  if (bytes) RFM_HIP_CHECK(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, stream));
+}
+
+int grid_for(const rfm_ctx* ctx, int64_t items) {
+  return int(std::max<int64_t>(1, std::min<int64_t>((items + kBlock - 1) / kBlock,
+                                                    int64_t(ctx->n_cu) * 16)));
+}
+
+rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_indices,
+                        const double* d_values, const double* d_y, const double* d_pscore,
+                        int64_t n_rows, int64_t n_features, int32_t n_factors, int64_t max_batch,
+                        int32_t hot_min_count) {
+  RFM_REQUIRE(ctx && d_indptr && d_y && d_pscore, "null pointer");
+  RFM_REQUIRE(n_rows >= 1 && n_features >= 1 && max_batch >= 1, "bad shape");
+  RFM_REQUIRE(n_rows < (int64_t(1) << 31), "too many rows");
+  const Shape shp = shape_for(n_factors);
+  RFM_REQUIRE(n_features < (int64_t(1) << 31) - 2, "n_features too large");
+  RFM_HIP_CHECK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+
+  const bool timing = env_int("RFM_PLAN_TIMING", 0) != 0;
+  auto t_prev = std::chrono::steady_clock::now();
+  const auto lap = [&](const char* what) {
+    if (!timing) return;
+    RFM_HIP_CHECK(hipStreamSynchronize(st));
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[plan] %s: %.2f ms\n", what,
+            std::chrono::duration<double, std::milli>(now - t_prev).count());
+    t_prev = now;
+  };
+
+  int64_t nnz = 0;
+  RFM_HIP_CHECK(hipMemcpyAsync(&nnz, d_indptr + n_rows, 8, hipMemcpyDeviceToHost, st));
+  RFM_HIP_CHECK(hipStreamSynchronize(st));
+  RFM_REQUIRE(nnz >= 0 && nnz < (int64_t(1) << 31) - kWave - (1 << 20), "nnz=%lld unsupported",
+              (long long)nnz);
+  RFM_REQUIRE(nnz == 0 || (d_indices && d_values), "null CSR arrays");
+  const size_t nz = size_t(nnz), nf = size_t(n_features), nr = size_t(n_rows);
+
+  auto plan = std::make_unique<rfm_fm_plan>();
+  plan->device = ctx->device;
+  plan->n_rows = n_rows;
+  plan->n_features = n_features;
+  plan->nnz = nnz;
+  plan->max_batch = max_batch;
+  plan->k = n_factors;
+
+  // ---- device passes over the entries ------------------------------------------------
+  DevBuf flags, row_of, key, pos, cstart, temp;
+  flags.alloc(16);
+  RFM_HIP_CHECK(hipMemsetAsync(flags.p, 0, 16, st));
+  row_of.alloc(std::max<size_t>(nz, 1) * 4);
+  plan->rows.alloc(nr * sizeof(RowRec));
+  hipLaunchKernelGGL(plan_rows_kernel, dim3(grid_for(ctx, n_rows)), dim3(kBlock), 0, st, d_indptr,
+                     d_indices, d_y, d_pscore, n_rows, nnz, n_features, plan->rows.as<RowRec>(),
+                     row_of.as<int32_t>(), flags.as<int32_t>());
+  RFM_HIP_CHECK(hipGetLastError());
+  int32_t h_flags[4] = {0, 0, 0, 0};
+  RFM_HIP_CHECK(hipMemcpyAsync(h_flags, flags.p, 16, hipMemcpyDeviceToHost, st));
+  RFM_HIP_CHECK(hipStreamSynchronize(st));
+  RFM_REQUIRE(!h_flags[0], "indptr not monotone / out of range (nnz %lld)", (long long)nnz);
+  RFM_REQUIRE(!h_flags[1], "a column index lies outside 0..%lld", (long long)n_features - 1);
+  lap("row records + checks");
+
+  key.alloc(std::max<size_t>(nz, 1) * 4);
+  pos.alloc(std::max<size_t>(nz, 1) * 4);
+  cstart.alloc((nf + 1) * 4);
+  if (nnz > 0) {
+    int bits = 1;
+    while ((int64_t(1) << bits) < n_features) ++bits;
+    size_t temp_bytes = 0;
+    const auto positions = rocprim::counting_iterator<int32_t>(0);
+    RFM_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, temp_bytes, d_indices, key.as<int32_t>(),
+                                            positions, pos.as<int32_t>(), nz, 0u, unsigned(bits),
+                                            st));
+    temp.alloc(temp_bytes);
+    RFM_HIP_CHECK(rocprim::radix_sort_pairs(temp.p, temp_bytes, d_indices, key.as<int32_t>(),
+                                            positions, pos.as<int32_t>(), nz, 0u, unsigned(bits),
+                                            st));
+  }
+  lap("sort by column");
+  hipLaunchKernelGGL(plan_starts_kernel, dim3(grid_for(ctx, nnz + 1)), dim3(kBlock), 0, st,
+                     key.as<int32_t>(), pos.as<int32_t>(), row_of.as<int32_t>(), nnz, n_features,
+                     cstart.as<int32_t>(), flags.as<int32_t>());
+  RFM_HIP_CHECK(hipGetLastError());
+  std::vector<int32_t> h_start(nf + 1);
+  RFM_HIP_CHECK(hipMemcpyAsync(h_start.data(), cstart.p, (nf + 1) * 4, hipMemcpyDeviceToHost, st));
+  RFM_HIP_CHECK(hipMemcpyAsync(h_flags, flags.p, 16, hipMemcpyDeviceToHost, st));
+  RFM_HIP_CHECK(hipStreamSynchronize(st));
+  RFM_REQUIRE(!h_flags[2], "a row names a column twice: sum duplicate entries first");
+  lap("column starts");
+
+  // ---- host: classes, slot bases, windows, crossing columns (O(n_features + windows)) --
+  const auto len = [&](size_t c) { return int64_t(h_start[c + 1]) - int64_t(h_start[c]); };
+  // hot class: expected entries per batch >= hot_min, most frequent first, LDS budget
+  std::vector<int32_t> hot_cols;
+  std::vector<int32_t> hot_rank(nf, -1);
+  if (hot_min_count >= 0) {
+    const int64_t hot_min = hot_min_count > 0 ? hot_min_count : kDefaultHotMinCount;
+    for (size_t c = 0; c < nf; ++c)
+      if (len(c) * max_batch >= hot_min * n_rows) hot_cols.push_back(int32_t(c));
+    std::stable_sort(hot_cols.begin(), hot_cols.end(),
+                     [&](int32_t x, int32_t y) { return len(size_t(x)) > len(size_t(y)); });
+    const size_t per_col = size_t(n_factors + 2) * 8;
+    // RFM_HOT_LDS_KB / RFM_MAX_HOT override the budget (tuning experiments only)
+    const size_t budget = size_t(env_int("RFM_HOT_LDS_KB", int(kHotLdsBudget >> 10))) << 10;
+    const size_t cap = std::min<size_t>(size_t(env_int("RFM_MAX_HOT", kMaxHot)), budget / per_col);
+    if (hot_cols.size() > cap) hot_cols.resize(cap);
+    std::sort(hot_cols.begin(), hot_cols.end());
+    for (size_t h = 0; h < hot_cols.size(); ++h) hot_rank[size_t(hot_cols[h])] = int32_t(h);
+  }
+  std::vector<int64_t> cptr(nf + 1, 0);  // slots of the sparse class, column-major
+  std::vector<int32_t> colinfo(nf);
+  for (size_t c = 0; c < nf; ++c) {
+    cptr[c + 1] = cptr[c] + (hot_rank[c] >= 0 ? 0 : len(c));
+    colinfo[c] = hot_rank[c] >= 0 ? kHotTag + hot_rank[c] : int32_t(cptr[c] - int64_t(h_start[c]));
+  }
+  const int64_t n_slots = cptr[nf];
+  const size_t ns = size_t(n_slots);
+  // fixed slot windows (one per lane group of fm_consume_kernel) and the columns that cross a
+  // window border, with the carry rows they collect in window order
+  const int64_t WIN = window_slots(shp.lpr);
+  const int64_t n_win = (n_slots + WIN - 1) / WIN;
+  RFM_REQUIRE(n_win * 2 < (int64_t(1) << 31), "too many slot windows");
+  std::vector<WinInfo> win(size_t(n_win) + 1, WinInfo{0, 0, 0, 0});
+  {
+    size_t cf = 0, cl = 0;  // column cursors of the windows' first and last slots
+    for (int64_t w = 0; w < n_win; ++w) {
+      const int64_t b0 = w * WIN, e0 = std::min(n_slots, b0 + WIN);
+      while (cptr[cf + 1] <= b0) ++cf;
+      if (cl < cf) cl = cf;
+      while (cptr[cl + 1] <= e0 - 1) ++cl;
+      int32_t flags_w = 0;
+      if (cptr[cf] < b0 || cptr[cf + 1] > e0) flags_w |= 1;
+      if (cl != cf && cptr[cl + 1] > e0) flags_w |= 2;
+      win[size_t(w)] = WinInfo{int32_t(cf), int32_t(cl), flags_w, 0};
+    }
+  }
+  std::vector<CrossCol> cross_short, cross_long;
+  std::vector<int32_t> carry_idx;
+  for (size_t c = 0; c < nf; ++c) {
+    const int64_t b0 = cptr[c], e0 = cptr[c + 1];
+    if (e0 <= b0) continue;
+    const int64_t wf = b0 / WIN, wl = (e0 - 1) / WIN;
+    if (wf == wl) continue;
+    CrossCol cc{int32_t(c), int32_t(carry_idx.size()), 0, 0};
+    for (int64_t w = wf; w <= wl; ++w) {
+      const int which = win[size_t(w)].first_col == int32_t(c) ? 0 : 1;
+      carry_idx.push_back(int32_t(w * 2 + which));
+      cc.idx_count++;
+    }
+    (cc.idx_count <= kShortCross ? cross_short : cross_long).push_back(cc);
+  }
+  std::vector<CrossCol> cross(cross_short);
+  cross.insert(cross.end(), cross_long.begin(), cross_long.end());
+  lap("classes, windows, crossing lists (host)");
+
+  // ---- entry and slot records ----------------------------------------------------------
+  plan->n_slots = n_slots;
+  plan->n_win = int32_t(n_win);
+  plan->n_cross_short = int32_t(cross_short.size());
+  plan->n_cross_long = int32_t(cross_long.size());
+  plan->n_hot = int32_t(hot_cols.size());
+  plan->h_hot_cols = hot_cols;
+  plan->fwd_grid_max = forward_grid(ctx, max_batch, n_factors);
+  DevBuf d_colinfo;
+  upload(d_colinfo, colinfo.data(), nf * 4, st);
+  plan->ent.alloc((nz + 1) * sizeof(Entry));  // +1: clamp target of empty logs
+  RFM_HIP_CHECK(hipMemsetAsync(plan->ent.as<Entry>() + nz, 0, sizeof(Entry), st));
+  plan->slots.alloc((ns + 256) * sizeof(SlotRec));  // padded by one window
+  RFM_HIP_CHECK(hipMemsetAsync(plan->slots.as<SlotRec>() + ns, 0, 256 * sizeof(SlotRec), st));
+  if (nnz > 0) {
+    hipLaunchKernelGGL(plan_scatter_kernel, dim3(grid_for(ctx, nnz)), dim3(kBlock), 0, st,
+                       key.as<int32_t>(), pos.as<int32_t>(), d_values, d_colinfo.as<int32_t>(),
+                       nnz, plan->ent.as<Entry>(), plan->slots.as<SlotRec>());
+    RFM_HIP_CHECK(hipGetLastError());
+  }
+  upload(plan->win, win.data(), win.size() * sizeof(WinInfo), st);
+  upload(plan->cross, cross.data(), cross.size() * sizeof(CrossCol), st);
+  upload(plan->carry_idx, carry_idx.data(), carry_idx.size() * 4, st);
+  upload(plan->hot_cols, hot_cols.data(), hot_cols.size() * 4, st);
+  plan->slot_t.alloc((ns + 256) * 4);
+  RFM_HIP_CHECK(hipMemsetAsync(plan->slot_t.p, 0xFF, plan->slot_t.bytes, st));
+  // carry rows [n_win*2][k+3]; stamp 0 never matches a step id (they start at 1)
+  plan->carries.alloc(std::max<size_t>(size_t(n_win) * 2, 1) * size_t(n_factors + 3) * 8);
+  RFM_HIP_CHECK(hipMemsetAsync(plan->carries.p, 0, plan->carries.bytes, st));
+  plan->hot_slab.alloc(size_t(kMaxFwdGrid) * std::max<size_t>(hot_cols.size(), 1) *
+                       size_t(n_factors + 2) * 8);
+  plan->hot_part.alloc(std::max<size_t>(hot_cols.size(), 1) * kHotParts * size_t(n_factors + 2) * 8);
+  plan->err_partial.alloc(size_t(kMaxFwdGrid) * 8);
+  plan->Q.alloc(size_t(max_batch) * size_t(n_factors) * 8);
+  plan->err.alloc(size_t(max_batch) * 8);
+  // the host vectors and the transient device buffers die at scope exit: wait for the stream
+  RFM_HIP_CHECK(hipStreamSynchronize(st));
+  lap("entry / slot records, uploads, scratch");
+  return plan.release();
+}
+
+}  // namespace
+}  // namespace rfm
+
+using namespace rfm;
+
+extern "C" {
+
+int32_t rfm_fm_plan_create_device(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_indices,
+                                  const double* d_values, const double* d_y,
+                                  const double* d_pscore, int64_t n_rows, int64_t n_features,
+                                  int32_t n_factors, int64_t max_batch, int32_t hot_min_count,
+                                  rfm_fm_plan** out) {
+  return guarded([&] {
+    RFM_REQUIRE(out, "null output pointer");
+    *out = build_plan(ctx, d_indptr, d_indices, d_values, d_y, d_pscore, n_rows, n_features,
+                      n_factors, max_batch, hot_min_count);
+  });
+}
+
+int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t* h_indices,
+                           const double* h_values, const double* h_y, const double* h_pscore,
+                           int64_t n_rows, int64_t n_features, int32_t n_factors,
+                           int64_t max_batch, int32_t hot_min_count, rfm_fm_plan** out) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx && h_indptr && h_y && h_pscore && out, "null pointer");
+    RFM_REQUIRE(n_rows >= 1 && n_features >= 1 && max_batch >= 1, "bad shape");
+    const int64_t nnz = h_indptr[n_rows];
+    RFM_REQUIRE(nnz >= 0 && nnz < (int64_t(1) << 31), "nnz=%lld unsupported", (long long)nnz);
+    RFM_REQUIRE(nnz == 0 || (h_indices && h_values), "null CSR arrays");
+    RFM_HIP_CHECK(hipSetDevice(ctx->device));
+    // a transient device copy of the log; the plan is built from it on the device
+    DevBuf indptr, indices, values, y, p;
+    const auto up = [&](DevBuf& dst, const void* src, size_t bytes) {
+      dst.alloc(bytes);
+      if (bytes) RFM_HIP_CHECK(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    };
+    up(indptr, h_indptr, size_t(n_rows + 1) * 8);
+    up(indices, h_indices, size_t(nnz) * 4);
+    up(values, h_values, size_t(nnz) * 8);
+    up(y, h_y, size_t(n_rows) * 8);
+    up(p, h_pscore, size_t(n_rows) * 8);
+    *out = build_plan(ctx, indptr.as<int64_t>(), indices.as<int32_t>(), values.as<double>(),
+                      y.as<double>(), p.as<double>(), n_rows, n_features, n_factors, max_batch,
+                      hot_min_count);
+  });
+}
+
+int32_t rfm_fm_plan_destroy(rfm_fm_plan* plan) {
+  return guarded([&] {
+    if (!plan) return;
+    (void)hipSetDevice(plan->device);
+    delete plan;
+  });
+}
+
+int32_t rfm_fm_plan_info(const rfm_fm_plan* plan, int64_t* h_out8) {
+  return guarded([&] {
+    RFM_REQUIRE(plan && h_out8, "null pointer");
+    h_out8[0] = plan->n_win;
+    h_out8[1] = plan->n_cross_short + plan->n_cross_long;
+    h_out8[2] = plan->n_hot;
+    h_out8[3] = plan->nnz;
+    h_out8[4] = int64_t(plan->device_bytes());
+    h_out8[5] = plan->fwd_grid_max;
+    h_out8[6] = plan->n_slots;
+    h_out8[7] = 0;
+  });
+}
+
+int32_t rfm_fm_plan_hot_columns(const rfm_fm_plan* plan, int32_t* h_out, int32_t capacity) {
+  return guarded([&] {
+    RFM_REQUIRE(plan && (h_out || capacity == 0), "null pointer");
+    RFM_REQUIRE(capacity >= plan->n_hot, "capacity %d < %d hot columns", capacity, plan->n_hot);
+    std::copy(plan->h_hot_cols.begin(), plan->h_hot_cols.end(), h_out);
+  });
+}
+
+}  // extern "C"

@@ -28,15 +28,17 @@ class FmPlan:
 
     def __init__(self, rt: Runtime, csr: DeviceCSR, labels, pscores, n_factors: int, max_batch: int,
                  hot_min_count: int = 0):
+        """``labels`` / ``pscores``: host arrays, or float64 device tensors the caller already
+        holds.  The plan is built on the device from the device copy of the log."""
         self.rt = rt
-        y = np.ascontiguousarray(labels, dtype=np.float64)
-        p = np.ascontiguousarray(pscores, dtype=np.float64)
+        y = labels if hasattr(labels, "data_ptr") else rt.upload(np.asarray(labels), dtype=np.float64)
+        p = pscores if hasattr(pscores, "data_ptr") else rt.upload(np.asarray(pscores), dtype=np.float64)
         if y.shape[0] != csr.shape[0] or p.shape[0] != csr.shape[0]:
             raise ValueError("labels / pscores do not match the number of rows")
         handle = C.c_void_p()
-        _lib.check(rt.lib.rfm_fm_plan_create(
-            rt.ctx, csr.h_indptr.ctypes.data, csr.h_indices.ctypes.data, csr.h_values.ctypes.data,
-            y.ctypes.data, p.ctypes.data, csr.shape[0], csr.shape[1], n_factors, max_batch,
+        _lib.check(rt.lib.rfm_fm_plan_create_device(
+            rt.ctx, csr.indptr.data_ptr(), csr.indices.data_ptr(), csr.values.data_ptr(),
+            y.data_ptr(), p.data_ptr(), csr.shape[0], csr.shape[1], n_factors, max_batch,
             hot_min_count, C.byref(handle)))
         self.handle = handle
 
@@ -126,8 +128,7 @@ class FactorizationMachines(PointwiseBaseRecommender):
         va = DeviceCSR(rt, val["features"])
         vy = rt.upload(np.asarray(val["labels"]), dtype=np.float64)
         vp = rt.upload(np.asarray(val["pscores"]), dtype=np.float64)
-        plan = FmPlan(rt, tr, train["labels"], train["pscores"], self.n_factors, self.batch_size,
-                      self.hot_min_count)
+        plan = FmPlan(rt, tr, y, p, self.n_factors, self.batch_size, self.hot_min_count)
         tl = rt.empty((self.n_epochs,), y.dtype)
         vl = rt.empty((self.n_epochs,), y.dtype)
         # an empty validation set: the reference's mean over no rows is nan (src/base.py:61)

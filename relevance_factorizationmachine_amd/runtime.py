@@ -151,33 +151,118 @@ def sample_batches(n_rows: int, batch_size: int, epoch_begin: int, n_epochs: int
     return out
 
 
-class BatchIdStream:
-    """The row-id lists of a whole ``fit()`` in chunks of iterations: a chunk is sampled
-    on the host (``rfm_sample_batches``, exact ``resample`` ids) while the GPU works on the
-    chunk before it, and uploaded when that one has been enqueued (the
-    Mersenne-Twister shuffle is inherently sequential per iteration, so it stays on the host
-    cores -- one iteration per thread -- and is overlapped rather than moved)."""
+class _IdCache:
+    """Row ids of iteration ``epoch`` of a log of ``n_rows`` rows depend on nothing else
+    (``resample(..., random_state=epoch)``), and the drivers fit several models on the same
+    log (``search_params`` then the final runs; FM and MF; IPS and Naive): keep what has
+    been sampled, the longest batch per (n_rows, epoch), up to ``CAP_BYTES``."""
 
-    CHUNK_IDS = 1 << 23  # ids per chunk: 32 MiB of int32
+    CAP_BYTES = 256 << 20
+
+    def __init__(self):
+        import threading
+
+        self._lock = threading.Lock()
+        self._rows: Dict[Tuple[int, int], np.ndarray] = {}
+        self._bytes = 0
+
+    def clear(self) -> None:
+        with self._lock:
+            self._rows.clear()
+            self._bytes = 0
+
+    def get(self, n_rows: int, batch_size: int, first: int, count: int) -> Optional[np.ndarray]:
+        with self._lock:
+            rows = [self._rows.get((n_rows, e)) for e in range(first, first + count)]
+        if any(r is None or r.shape[0] < batch_size for r in rows):
+            return None
+        return np.stack([r[:batch_size] for r in rows]) if rows else np.empty((0, batch_size), np.int32)
+
+    def put(self, n_rows: int, first: int, ids: np.ndarray) -> None:
+        with self._lock:
+            for j in range(ids.shape[0]):
+                key = (n_rows, first + j)
+                old = self._rows.get(key)
+                if old is not None and old.shape[0] >= ids.shape[1]:
+                    continue
+                if self._bytes + ids[j].nbytes > self.CAP_BYTES:
+                    return
+                self._bytes += ids[j].nbytes - (old.nbytes if old is not None else 0)
+                self._rows[key] = ids[j].copy()
+
+
+ID_CACHE = _IdCache()
+
+
+class BatchIdStream:
+    """The row-id lists of a whole ``fit()`` in chunks of iterations (the
+    Mersenne-Twister shuffle is inherently sequential per iteration, so it stays on the host
+    cores -- one iteration per thread -- and is overlapped rather than moved).  The first,
+    small chunk is sampled in the constructor (a batch larger than the log raises there,
+    before anything is uploaded); a background thread samples the rest, exact ``resample``
+    ids, while the caller uploads the log, builds the plan and the GPU trains."""
+
+    CHUNK_IDS = 1 << 23   # most ids per chunk: 32 MiB of int32
+    FIRST_ITERS = 16      # iterations of the first chunk: the GPU starts after one sampler round
+    CHUNK_ITERS = 64      # iterations of the later chunks
+    QUEUE_DEPTH = 4       # sampled chunks waiting for the consumer
 
     def __init__(self, rt: Runtime, n_rows: int, batch_size: int, n_epochs: int):
+        import queue
+        import threading
+
         self.rt, self.n_rows, self.batch_size, self.n_epochs = rt, n_rows, batch_size, n_epochs
-        self.chunk = int(max(1, min(max(n_epochs, 1), self.CHUNK_IDS // max(batch_size, 1))))
-        # the first chunk now: a batch larger than the log raises before anything is uploaded
-        self._host = sample_batches(n_rows, batch_size, 0, min(self.chunk, n_epochs))
+        most = int(max(1, self.CHUNK_IDS // max(batch_size, 1)))
+        cuts, at = [], 0
+        while at < n_epochs:
+            size = min(self.FIRST_ITERS if at == 0 else self.CHUNK_ITERS, most, n_epochs - at)
+            cuts.append((at, size))
+            at += size
+        self._cuts = cuts
+        self._first = self._sample(*cuts[0]) if cuts else None
+        self._queue: "queue.Queue" = queue.Queue(maxsize=self.QUEUE_DEPTH)
+        self._stop = False
+        self._thread = None
+        if len(cuts) > 1:
+            self._thread = threading.Thread(target=self._work, name="rfm-sampler", daemon=True)
+            self._thread.start()
+
+    def _sample(self, first: int, count: int) -> np.ndarray:
+        got = ID_CACHE.get(self.n_rows, self.batch_size, first, count)
+        if got is None:
+            got = sample_batches(self.n_rows, self.batch_size, first, count)
+            ID_CACHE.put(self.n_rows, first, got)
+        return got
+
+    def _work(self) -> None:
+        try:
+            for first, count in self._cuts[1:]:
+                if self._stop:
+                    return
+                self._queue.put((first, self._sample(first, count)))
+        except BaseException as exc:  # noqa: BLE001 -- handed to the consumer
+            self._queue.put((None, exc))
 
     def chunks(self):
-        """Yields ``(first_epoch, host_ids (count, B), device_ids)``; the next chunk is
-        sampled after the consumer has enqueued the work of the current one."""
-        first = 0
-        while first < self.n_epochs:
-            host = self._host
-            dev = self.rt.upload(host)
-            yield first, host, dev
-            first += host.shape[0]
-            if first < self.n_epochs:
-                self._host = sample_batches(self.n_rows, self.batch_size, first,
-                                            min(self.chunk, self.n_epochs - first))
+        """Yields ``(first_epoch, host_ids (count, B), device_ids)`` in order."""
+        try:
+            for i, (first, _) in enumerate(self._cuts):
+                if i == 0:
+                    host = self._first
+                else:
+                    got_first, host = self._queue.get()
+                    if got_first is None:
+                        raise host
+                    assert got_first == first
+                yield first, host, self.rt.upload(host)
+        finally:
+            self._stop = True
+            if self._thread is not None:
+                while self._thread.is_alive():  # unblock a producer waiting on a full queue
+                    try:
+                        self._queue.get_nowait()
+                    except Exception:  # noqa: BLE001 -- empty
+                        self._thread.join(timeout=0.01)
 
 
 def mf_schedule(users: np.ndarray, items: np.ndarray, n_users: int, n_items: int):

@@ -695,3 +695,72 @@ def test_predict_sees_in_place_edits_of_a_cached_matrix(rfm):
     assert rel_err(model.predict(X), cpu_ref.fm_predict(X, w0, w, V)) < TIGHT
     X.data[:] = X.data * 2.0 + 0.25
     assert rel_err(model.predict(X), cpu_ref.fm_predict(X, w0, w, V)) < TIGHT
+
+
+def test_plan_builders_agree_and_reject_malformed_logs(rfm):
+    """The training plan is built on the device, from the device copy of the log or from
+    the caller's host arrays (rfm_fm_plan_create uploads a transient copy): both give the
+    same step, and both reject what SciPy would not produce."""
+    pkg, _lib, runtime, rt = rfm
+    from relevance_factorizationmachine_amd.fm import FmPlan
+    rng = np.random.default_rng(13)
+    log = _random_log(rng, 3000, 200, 0.04, 2)
+    X, k, B = log["features"], 10, 1500
+    dev = runtime.DeviceCSR(rt, X)
+    y, p = rt.upload(log["labels"], dtype=np.float64), rt.upload(log["pscores"], dtype=np.float64)
+    hy, hp = log["labels"].astype(np.float64), log["pscores"].astype(np.float64)
+    ids = rt.upload(cpu_ref.batch_ids(3000, B, 0).astype(np.int32))
+
+    def host_plan(indptr, indices, values, n_rows=3000, n_cols=200):
+        h = C.c_void_p()
+        _lib.check(rt.lib.rfm_fm_plan_create(rt.ctx, indptr.ctypes.data, indices.ctypes.data, values.ctypes.data,
+                                             hy.ctypes.data, hp.ctypes.data, n_rows, n_cols, k, B, 0, C.byref(h)))
+        return h
+
+    results = []
+    for which in ("device", "host"):
+        model = _fm(pkg, n_factors=k, n_features=200, lr=1e-4, batch_size=B)
+        if which == "device":
+            plan = FmPlan(rt, dev, y, p, k, B)
+            handle = plan.handle
+        else:
+            handle = host_plan(dev.h_indptr, dev.h_indices, dev.h_values)
+        _lib.check(rt.lib.rfm_fm_step(rt.ctx, handle, dev.indptr.data_ptr(), dev.indices.data_ptr(),
+                                      dev.values.data_ptr(), y.data_ptr(), p.data_ptr(), ids.data_ptr(), B,
+                                      model.w0.dev.data_ptr(), model.w.dev.data_ptr(), model.V.dev.data_ptr(), 1e-4))
+        rt.sync()
+        results.append((model.V(), model.w(), model.w0()))
+        if which == "device":
+            info = plan.info()
+            assert info["nnz"] == X.nnz and info["slots"] + 0 <= X.nnz and info["hot_columns"] >= 2
+            plan.close()
+        else:
+            rt.lib.rfm_fm_plan_destroy(handle)
+    w0, w, V = cpu_ref.fm_init(12345, 200, k)
+    rows = cpu_ref.batch_ids(3000, B, 0)
+    cpu_ref.fm_step_closed(X[rows], log["labels"][rows], log["pscores"][rows], w0, w, V, 1e-4)
+    for Vg, wg, w0g in results:
+        assert rel_err(Vg, V) < TIGHT and rel_err(wg, w) < TIGHT and rel_err(w0g, w0) < TIGHT
+    assert rel_err(results[0][0], results[1][0]) < 1e-13  # same plan either way (hot sums: LDS atomics)
+
+    indptr, indices, values = dev.h_indptr.copy(), dev.h_indices.copy(), dev.h_values.copy()
+    bad = indices.copy()
+    r = int(np.flatnonzero(np.diff(indptr) >= 2)[0])
+    bad[indptr[r] + 1] = bad[indptr[r]]  # a row names a column twice
+    with pytest.raises(ValueError, match="twice"):
+        host_plan(indptr, bad, values)
+    bad = indices.copy()
+    bad[7] = 200
+    with pytest.raises(ValueError, match="column index"):
+        host_plan(indptr, bad, values)
+    bad = indices.copy()
+    bad[7] = -3
+    with pytest.raises(ValueError, match="column index"):
+        host_plan(indptr, bad, values)
+    badp = indptr.copy()
+    badp[5], badp[6] = badp[6], badp[5] - 1
+    with pytest.raises(ValueError, match="monotone"):
+        host_plan(badp, indices, values)
+    # a log without entries still gives a plan (rows score sigmoid(w0))
+    empty = host_plan(np.zeros(4, np.int64), np.zeros(1, np.int32), np.zeros(1), n_rows=3, n_cols=5)
+    rt.lib.rfm_fm_plan_destroy(empty)

@@ -368,6 +368,23 @@ int32_t rfm_val_dcg(rfm_ctx* ctx, const double* d_scores, const int32_t* d_seg_p
                     const int32_t* d_rows, const double* d_labels, const double* d_pscores,
                     int32_t n_segments, int32_t k, double* d_user_scratch, double* d_out);
 
+/* ---- test-set metrics -------------------------------------
+ * The ranking half of TestEvaluator.evaluate (utils/evaluate.py:80-127): per user
+ * group (same grouping arrays as rfm_val_dcg; d_items = item id per position, may
+ * be NULL) the positions of the k best-scored rows, d_out_pos[g*k + r] = position
+ * of rank r or -1 past the group's rows, same tie rule (later position first).
+ * d_out_flags[g]: bit 0 = the group has a positive label (the others are left out
+ * of every metric, evaluate.py:99-100); bit 1 = the first k ranks depend on how
+ * equal scores are ordered (a tie between rows of different label, propensity or
+ * item inside the first k ranks or across rank k, or a NaN score) -- the Python
+ * mirror ranks exactly those groups again with NumPy's own sort.  DCG@K, Recall,
+ * MAP, mean exposure, CatalogCoverage and Gini (utils/metrics.py:9-166) are sums
+ * over these n_segments x k positions. */
+int32_t rfm_topk_users(rfm_ctx* ctx, const double* d_scores, const int32_t* d_seg_ptr,
+                       const int32_t* d_rows, const double* d_labels, const double* d_pscores,
+                       const int32_t* d_items, int32_t n_segments, int32_t k, int32_t* d_out_pos,
+                       int32_t* d_out_flags);
+
 #ifdef __cplusplus
 }
 #endif

@@ -116,6 +116,7 @@ SIGNATURES = {
     "rfm_mf_sgd_hogwild": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _i32, _f64,
                            _f64],
     "rfm_val_dcg": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
+    "rfm_topk_users": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
 }
 
 _lib = None

@@ -285,3 +285,162 @@ def device_frame(rt: Runtime, evaluator, estimator: str, n_scores: int) -> Optio
         return None
     users, labels, pscores, k = got
     return DeviceValFrame(rt, users, labels, pscores, k)
+
+
+# ---------------------------------------------------------------------------
+# test-set metrics: TestEvaluator on device-ranked rows
+# ---------------------------------------------------------------------------
+TEST_METRICS = ("Recall", "MAP", "DCG", "ME", "CatalogCoverage", "Gini")  # utils/metrics.py:169-178
+
+
+class TestFrame:
+    """A test frame grouped by user and the metrics of ``TestEvaluator.evaluate``
+    (``utils/evaluate.py:80-127``) from the positions of every user's best ``max(K)`` rows.
+    Host only: the ranking is what the device does (``DeviceTestEvaluator``); the metrics
+    themselves are sums over ``n_users x max(K)`` values."""
+
+    __test__ = False  # not a pytest class
+
+    def __init__(self, users, items, labels, pscores, K, used_metrics, n_items: int):
+        self.K = tuple(int(k) for k in K)
+        if not self.K or min(self.K) < 1:
+            raise ValueError("K (ranking positions) must be positive")
+        self.kmax = max(self.K)
+        # the reference always reports ME, then the metrics it was asked for (evaluate.py:66-78)
+        self.names = ["ME"]
+        for name in used_metrics:
+            if name not in TEST_METRICS:
+                raise ValueError(f"metric_name must be in {TEST_METRICS}. metric_name: '{name}'")
+            if name not in self.names:
+                self.names.append(name)
+        self.n_items = int(n_items)
+        users = np.asarray(users)
+        n = users.shape[0]
+        self.n_rows = int(n)
+        self.h_order, self.h_seg_ptr = group_by_user(users)
+        self.n_segments = int(self.h_seg_ptr.shape[0] - 1)
+        cols = []
+        for arr, dt in ((labels, np.float64), (pscores, np.float64), (items, np.int64)):
+            arr = np.asarray(arr, dtype=dt)
+            if arr.shape != (n,):
+                raise ValueError("frame columns must match its rows")
+            cols.append(arr[self.h_order] if n else arr)
+        self.h_labels, self.h_pscores, self.h_items = cols
+        self.h_ysum = (np.add.reduceat(self.h_labels, self.h_seg_ptr[:-1].astype(np.int64))
+                       if n else np.zeros(0))
+
+    def host_topk(self, scores: np.ndarray, g: int) -> np.ndarray:
+        """Positions of user ``g``'s best rows exactly as the reference ranks them
+        (``argsort()[::-1]``, whatever order NumPy leaves equal scores in)."""
+        lo, hi = int(self.h_seg_ptr[g]), int(self.h_seg_ptr[g + 1])
+        ranked = scores[self.h_order[lo:hi]].argsort()[::-1][: self.kmax]
+        out = np.full(self.kmax, -1, dtype=np.int64)
+        out[: ranked.shape[0]] = lo + ranked
+        return out
+
+    def metrics(self, pos: np.ndarray, flags: np.ndarray, scores: np.ndarray) -> dict:
+        """``{metric: [value per K]}`` from the device's ``pos [n_users][kmax]`` / ``flags``
+        (``rfm_topk_users``); users flagged order-dependent are ranked again on the host."""
+        pos = np.asarray(pos, dtype=np.int64).reshape(self.n_segments, self.kmax).copy()
+        flags = np.asarray(flags)
+        for g in np.flatnonzero(flags & 2):
+            pos[g] = self.host_topk(scores, int(g))
+        counted = np.flatnonzero(flags & 1)
+        P = pos[counted]
+        valid = P >= 0
+        safe = np.where(valid, P, 0)
+        Y = np.where(valid, self.h_labels[safe] if self.n_rows else 0.0, 0.0)
+        PS = np.where(valid, self.h_pscores[safe] if self.n_rows else 0.0, np.nan)
+        IT = np.where(valid, self.h_items[safe] if self.n_rows else 0, -1)
+        ysum = self.h_ysum[counted] if self.n_rows else np.zeros(0)
+        out = {}
+        with np.errstate(invalid="ignore", divide="ignore"):
+            for name in self.names:
+                vals = []
+                for k in self.K:
+                    if name == "ME":  # utils/metrics.py:110-126
+                        vals.append(_nanmean(PS[:, k - 1]))
+                    elif name == "DCG":  # utils/metrics.py:83-107
+                        disc = np.log2(np.arange(1, k) + 1)
+                        vals.append(_nanmean(0.0 + Y[:, 0] + np.sum(Y[:, 1:k] / disc[None, :], axis=1)))
+                    elif name == "Recall":  # utils/metrics.py:32-50
+                        vals.append(_nanmean(np.sum(Y[:, :k], axis=1) / ysum))
+                    elif name == "MAP":  # utils/metrics.py:9-29
+                        hits = (Y[:, :k] >= 1) & valid[:, :k]
+                        prec = np.cumsum(Y[:, :k], axis=1) / np.arange(1, k + 1)[None, :]
+                        vals.append(_nanmean(np.sum(np.where(hits, prec, 0.0), axis=1)))
+                    elif name == "CatalogCoverage":  # utils/metrics.py:151-166
+                        rec = IT[:, :k][valid[:, :k]]
+                        vals.append(len(np.unique(rec)) / self.n_items)
+                    else:  # Gini, utils/metrics.py:129-148
+                        rec = IT[:, :k][valid[:, :k]]
+                        rec = rec[(rec >= 0) & (rec < self.n_items)]
+                        freqs = np.sort(np.bincount(rec, minlength=self.n_items), kind="merge")
+                        idx = np.arange(1, self.n_items + 1)
+                        vals.append(float(np.sum((2 * idx - self.n_items - 1) * freqs)
+                                          / (self.n_items * np.sum(freqs))))
+                out[name] = vals
+        return out
+
+
+def _nanmean(a: np.ndarray) -> float:
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", category=RuntimeWarning)  # mean of no users is nan
+        return float(np.nanmean(a)) if a.size else float("nan")
+
+
+class DeviceTestEvaluator:
+    """``TestEvaluator`` (``utils/evaluate.py:42-156``) with the per-user ranking on the
+    device: same constructor fields (``interaction_df`` with the columns user / item / label /
+    pscore, ``features``, ``K``, ``used_metrics``, ``n_items``), same ``evaluate(y_scores)``
+    result -- ``{metric: [value per K]}`` with ``ME`` always present -- and the same side
+    effect (``interaction_df["y_score"]``)."""
+
+    def __init__(self, interaction_df, features, K, used_metrics, n_items: int, rt: Optional[Runtime] = None):
+        from collections import defaultdict
+
+        self.interaction_df, self.features = interaction_df, features
+        self.K, self.used_metrics, self.n_items = K, used_metrics, n_items
+        self._defaultdict = defaultdict
+        self.rt = rt or Runtime.get()
+        df = interaction_df
+        self.frame = TestFrame(df["user"], df["item"], df["label"], df["pscore"], K, used_metrics, n_items)
+        fr, up = self.frame, self.rt.upload
+        n = fr.n_rows
+        self._rows = up(fr.h_order if n else np.zeros(1, np.int32))
+        self._seg = up(fr.h_seg_ptr)
+        self._labels = up(fr.h_labels if n else np.zeros(1))
+        self._pscores = up(fr.h_pscores if n else np.zeros(1))
+        self._items = up((fr.h_items if n else np.zeros(1)).astype(np.int32))
+        self.host_users = 0  # users ranked again on the host in the last evaluate()
+
+    def topk(self, y_scores):
+        """``(pos [n_users][max K], flags [n_users])`` of host or device scores (frame order)."""
+        torch = __import__("torch")
+        rt, fr = self.rt, self.frame
+        d = y_scores if hasattr(y_scores, "data_ptr") else rt.upload(np.asarray(y_scores, dtype=np.float64))
+        if d.shape[0] != fr.n_rows:
+            raise ValueError(f"{d.shape[0]} scores for a frame of {fr.n_rows} rows")
+        pos = rt.empty((max(fr.n_segments, 1), fr.kmax), torch.int32)
+        flags = rt.empty((max(fr.n_segments, 1),), torch.int32)
+        _lib.check(rt.lib.rfm_topk_users(
+            rt.ctx, d.data_ptr(), self._seg.data_ptr(), self._rows.data_ptr(), self._labels.data_ptr(),
+            self._pscores.data_ptr(), self._items.data_ptr(), fr.n_segments, fr.kmax, pos.data_ptr(),
+            flags.data_ptr()))
+        rt.sync()
+        return pos.cpu().numpy()[: fr.n_segments], flags.cpu().numpy()[: fr.n_segments]
+
+    def evaluate(self, y_scores):
+        host_scores = y_scores.cpu().numpy() if hasattr(y_scores, "data_ptr") else np.asarray(y_scores, dtype=np.float64)
+        pos, flags = self.topk(y_scores)
+        self.host_users = int(np.count_nonzero(flags & 2))
+        try:
+            self.interaction_df["y_score"] = host_scores  # utils/evaluate.py:141
+        except Exception:  # noqa: BLE001 -- a read-only frame
+            pass
+        results = self._defaultdict(list)
+        for name, vals in self.frame.metrics(pos, flags, host_scores).items():
+            results[name] = list(vals)
+        return results

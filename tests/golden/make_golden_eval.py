@@ -48,6 +48,23 @@ def main() -> None:
     te = TestEvaluator(interaction_df=df.copy(), features={}, K=(1, 3, 5, 7, 9), used_metrics={"DCG"},
                        n_items=400)
     out["test_dcg"] = np.asarray(te.evaluate(scores)["DCG"])
+    # every metric TestEvaluator knows (utils/metrics.py:169-178) on the same frame and scores
+    te_all = TestEvaluator(interaction_df=df.copy(), features={}, K=(1, 3, 5, 7, 9),
+                           used_metrics={"DCG", "CatalogCoverage", "Recall", "MAP", "Gini"}, n_items=400)
+    res = te_all.evaluate(scores)
+    assert set(res) == {"ME", "DCG", "CatalogCoverage", "Recall", "MAP", "Gini"}
+    for name, vals in res.items():
+        out[f"test_{name}"] = np.asarray(vals, dtype=np.float64)
+    # the drivers' own configuration (main_kuairec.py:76-82) on a frame of short users, where
+    # ME@K of a user with fewer than K rows is nan
+    short = rng.integers(0, 1200, size=n).astype(np.int64)
+    fr3 = dict(frame, user=short)
+    te3 = TestEvaluator(interaction_df=pd.DataFrame(fr3), features={}, K=[1, 3, 5, 7, 9],
+                        used_metrics={"CatalogCoverage", "DCG"}, n_items=400)
+    res3 = te3.evaluate(scores)
+    out["short_user"] = short
+    for name, vals in res3.items():
+        out[f"short_test_{name}"] = np.asarray(vals, dtype=np.float64)
 
     # ties that cannot matter: label and pscore are functions of the (rounded) score
     tied = np.round(scores, 2)

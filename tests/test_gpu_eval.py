@@ -345,3 +345,70 @@ def test_unrecognised_evaluators_stay_host_callbacks(ev):
 
     assert evaluate.device_frame(rt, Good(), "IPS", 4) is not None
     assert evaluate.device_frame(rt, Good(), "IPS", 5) is None  # scores would not match the frame
+
+
+# --------------------------------------------------------------------------
+# test-set metrics: rfm_topk_users + DeviceTestEvaluator
+# --------------------------------------------------------------------------
+def test_device_test_evaluator_matches_reference_fixture(ev):
+    """Every metric of the reference's TestEvaluator (outputs stored by make_golden_eval.py),
+    with the per-user ranking done by rfm_topk_users."""
+    import pandas as pd
+
+    evaluate, rt = ev
+    g = load_golden("val_dcg_distinct")
+    K = [1, 3, 5, 7, 9]
+    for prefix, users, used in (("test_", g["user"], {"DCG", "CatalogCoverage", "Recall", "MAP", "Gini"}),
+                                ("short_test_", g["short_user"], {"CatalogCoverage", "DCG"})):
+        df = pd.DataFrame({"user": users, "item": g["item"], "label": g["label"], "pscore": g["pscore"],
+                           "ones_pscore": np.ones(len(users))})
+        te = evaluate.DeviceTestEvaluator(interaction_df=df, features={}, K=K, used_metrics=used, n_items=400)
+        res = te.evaluate(g["scores"])
+        assert set(res) == {"ME"} | used and te.host_users == 0  # distinct scores: nothing redone
+        for m in res:
+            np.testing.assert_allclose(res[m], g[prefix + m], rtol=1e-13, atol=0, err_msg=prefix + m)
+        np.testing.assert_array_equal(df["y_score"].to_numpy(), g["scores"])  # the reference's side effect
+        # device-resident scores too
+        res2 = te.evaluate(rt.upload(g["scores"]))
+        assert {m: list(v) for m, v in res2.items()} == {m: list(v) for m, v in res.items()}
+    with pytest.raises(ValueError):
+        te.evaluate(g["scores"][:-1])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_device_test_evaluator_with_ties_equals_numpy_ranking(ev, seed):
+    """Tie-heavy scores (few distinct levels, saturated ones, NaNs), ragged users, users
+    shorter than K, users without positives: the device ranks, flags the users whose first
+    max(K) rows depend on the tie order, and those are ranked again with NumPy's own sort --
+    the result is the oracle's restatement of TestEvaluator.evaluate, metric by metric."""
+    evaluate, rt = ev
+    rng = np.random.default_rng(100 + seed)
+    n, n_users, n_items = 4000, [30, 400, 1500, 3, 800, 4000][seed], 90
+    frame = {"user": rng.integers(0, n_users, size=n) * 3 + 1, "item": rng.integers(0, n_items + 5, size=n),
+             "label": (rng.random(n) < [0.3, 0.05, 0.5, 0.3, 1.0, 0.2][seed]).astype(np.int64),
+             "pscore": np.round(rng.uniform(0.1, 1.0, size=n), 1 if seed % 2 else 3)}
+    levels = [5, 50, 3, 1000, 2, 7][seed]
+    scores = rng.integers(0, levels, size=n) / levels
+    scores[rng.random(n) < 0.1] = 1.0
+    if seed == 3:
+        scores[rng.integers(0, n, size=5)] = np.nan
+    K, used = (1, 2, 5, 10), ("DCG", "CatalogCoverage", "Recall", "MAP", "Gini")
+    te = evaluate.DeviceTestEvaluator(interaction_df=dict(frame), features={}, K=K, used_metrics=used,
+                                      n_items=n_items)
+    got = te.evaluate(scores)
+    want = cpu_ref.test_metrics(frame, scores, K, used, n_items)
+    for m in want:
+        np.testing.assert_allclose(got[m], want[m], rtol=1e-12, atol=0, equal_nan=True, err_msg=m)
+    # positions under the device's own rule (later row first among equal scores)
+    pos, flags = te.topk(scores)
+    fr = te.frame
+    for u in rng.integers(0, fr.n_segments, size=40):
+        lo, hi = fr.h_seg_ptr[u], fr.h_seg_ptr[u + 1]
+        sc = scores[fr.h_order[lo:hi]]
+        assert (flags[u] & 1) == int(fr.h_labels[lo:hi].sum() > 0)
+        if np.isnan(sc).any():
+            assert flags[u] & 2
+            continue
+        rank = np.argsort(sc, kind="stable")[::-1][: max(K)]
+        np.testing.assert_array_equal(pos[u][: len(rank)], lo + rank)
+        assert (pos[u][len(rank):] == -1).all()

@@ -157,3 +157,32 @@ def test_logloss_and_sigmoid_edges():
         float(g["loss_first3"]), rel=1e-14)
     s = load_golden("sigmoid_edges")
     np.testing.assert_array_equal(cpu_ref.sigmoid(s["x"]), s["y"])
+
+
+def test_test_evaluator_metrics_against_reference_outputs():
+    """Oracle restatement of TestEvaluator.evaluate (all six metrics, utils/metrics.py) and
+    the product's host half (TestFrame.metrics fed with NumPy-ranked positions) against
+    what the reference's TestEvaluator returned (tests/golden/make_golden_eval.py)."""
+    from relevance_factorizationmachine_amd.evaluate import TestFrame
+
+    g = load_golden("val_dcg_distinct")
+    K = (1, 3, 5, 7, 9)
+    cases = [("test_", g["user"], ("DCG", "CatalogCoverage", "Recall", "MAP", "Gini")),
+             ("short_test_", g["short_user"], ("CatalogCoverage", "DCG"))]
+    for prefix, users, used in cases:
+        frame = {"user": users, "item": g["item"], "label": g["label"], "pscore": g["pscore"]}
+        want = {m: g[prefix + m] for m in ("ME",) + used}
+        got = cpu_ref.test_metrics(frame, g["scores"], K, used, n_items=400)
+        assert set(got) == set(want)
+        for m in want:
+            np.testing.assert_allclose(got[m], want[m], rtol=1e-13, atol=0, err_msg=prefix + m)
+        tf = TestFrame(users, g["item"], g["label"], g["pscore"], K, used, 400)
+        pos = np.stack([tf.host_topk(g["scores"], u) for u in range(tf.n_segments)])
+        flags = (tf.h_ysum > 0).astype(np.int32)
+        got2 = tf.metrics(pos, flags, g["scores"])
+        assert list(got2)[0] == "ME" and set(got2) == set(want)
+        for m in want:
+            np.testing.assert_allclose(got2[m], want[m], rtol=1e-13, atol=0, err_msg="frame " + prefix + m)
+    np.testing.assert_allclose(g["test_DCG"], g["test_dcg"], rtol=0)  # same reference call, two fixtures
+    with pytest.raises(ValueError, match="metric_name"):
+        TestFrame(users, g["item"], g["label"], g["pscore"], K, {"NDCG"}, 400)

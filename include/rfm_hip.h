@@ -306,6 +306,20 @@ int32_t rfm_mf_sgd_levels_ex(rfm_ctx* ctx, const void* d_ex, const int32_t* h_le
                              double* d_Q, double* d_bu, double* d_bi, double b,
                              int32_t n_factors, double lr, double reg);
 
+/* ---- MF across GPUs: user-range partition ------------------
+ * NOT the reference's semantics (its batch is strictly sequential, src/mf.py:97-108;
+ * exact mode = one GPU or independent replicas).  Throughput mode: rank r runs the exact
+ * sequential SGD (rfm_mf_sgd_levels_ex) over the batch's examples whose USER lies in its
+ * range, in batch order, on its own replica of Q / b_i; P / b_u rows are only ever
+ * written by their owner.  After the batch each rank forms what its examples changed,
+ * rfm_mf_delta: d_out = d_cur - d_sync, the deltas are all-reduced (sum), and
+ * rfm_mf_merge: d_sync += d_total, d_cur = d_sync brings every replica to the same
+ * values.  With one rank nothing is exchanged and the result is the reference's. */
+int32_t rfm_mf_delta(rfm_ctx* ctx, const double* d_cur, const double* d_sync, double* d_out,
+                     int64_t count);
+int32_t rfm_mf_merge(rfm_ctx* ctx, double* d_cur, double* d_sync, const double* d_total,
+                     int64_t count);
+
 /* ---- multi-GPU exchange (RCCL over xGMI) ----------------------------------
  * The data-parallel FM step all-reduces the dense gradient buffer of rfm_fm_grad
  * (SURVEY.md 8e).  The Python mirror does that through torch.distributed (backend

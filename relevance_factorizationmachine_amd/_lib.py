@@ -113,6 +113,8 @@ SIGNATURES = {
                            C.POINTER(_i32)],
     "rfm_mf_sgd_levels_ex": [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _f64, _i32, _f64,
                              _f64],
+    "rfm_mf_delta": [_vp, _vp, _vp, _vp, _i64],
+    "rfm_mf_merge": [_vp, _vp, _vp, _vp, _i64],
     "rfm_mf_sgd_hogwild": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _i32, _f64,
                            _f64],
     "rfm_val_dcg": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],

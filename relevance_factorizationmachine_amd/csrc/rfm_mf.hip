@@ -554,6 +554,25 @@ static void mf_predict_launch(rfm_ctx* ctx, MfPredArgs a, double* d_out_loss) {
 
 using namespace rfm;
 
+// Replica merge of the user-partitioned MF mode: every rank runs the
+// exact sequential SGD on the examples of ITS users against its own replica of Q / b_i;
+// after the batch the replicas' changes are added up.
+//   delta: out = cur - sync                 (what this rank's examples changed)
+//   merge: sync += total; cur = sync        (total = all ranks' deltas, all-reduced)
+__global__ __launch_bounds__(256) void mf_delta_kernel(const double* cur, const double* sync,
+                                                      double* out, int64_t n) {
+  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256)
+    out[i] = cur[i] - sync[i];
+}
+__global__ __launch_bounds__(256) void mf_merge_kernel(double* cur, double* sync,
+                                                      const double* total, int64_t n) {
+  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
+    const double v = sync[i] + total[i];
+    sync[i] = v;
+    cur[i] = v;
+  }
+}
+
 extern "C" {
 
 int32_t rfm_mf_predict(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d_items,
@@ -780,6 +799,32 @@ int32_t rfm_mf_sgd_hogwild(rfm_ctx* ctx, const int32_t* d_users, const int32_t* 
                      a)
     RFM_FOR_SHAPE(s, RFM_CALL_HOG);
 #undef RFM_CALL_HOG
+    RFM_HIP_CHECK(hipGetLastError());
+  });
+}
+
+int32_t rfm_mf_delta(rfm_ctx* ctx, const double* d_cur, const double* d_sync, double* d_out,
+                     int64_t count) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx && count >= 0, "bad argument");
+    if (count == 0) return;
+    RFM_REQUIRE(d_cur && d_sync && d_out, "null pointer");
+    const int grid = int(std::min<int64_t>((count + 255) / 256, int64_t(ctx->n_cu) * 16));
+    hipLaunchKernelGGL(mf_delta_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_cur, d_sync, d_out,
+                       count);
+    RFM_HIP_CHECK(hipGetLastError());
+  });
+}
+
+int32_t rfm_mf_merge(rfm_ctx* ctx, double* d_cur, double* d_sync, const double* d_total,
+                     int64_t count) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx && count >= 0, "bad argument");
+    if (count == 0) return;
+    RFM_REQUIRE(d_cur && d_sync && d_total, "null pointer");
+    const int grid = int(std::min<int64_t>((count + 255) / 256, int64_t(ctx->n_cu) * 16));
+    hipLaunchKernelGGL(mf_merge_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_cur, d_sync,
+                       d_total, count);
     RFM_HIP_CHECK(hipGetLastError());
   });
 }

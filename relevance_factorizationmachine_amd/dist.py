@@ -295,3 +295,148 @@ class RowExchange:
         if stage_host is None:
             stage_host = backend != "nccl"
         return TorchRowComm(dist, world, rank, n_factors + 2, stage_host)
+
+
+# ---------------------------------------------------------------------------
+# MF across GPUs: user-range partition; NOT the reference's semantics
+# ---------------------------------------------------------------------------
+def user_ranges(n_users: int, world: int):
+    """First user of every rank's range (``world + 1`` entries, the last = ``n_users``)."""
+    import numpy as np
+
+    return np.array([n_users * r // world for r in range(world + 1)], dtype=np.int64)
+
+
+class MfUserPartitionStep:
+    """One mini-batch of logistic MF over ``world`` ranks.
+
+    The reference's batch is strictly sequential (``src/mf.py:97-108``), so it does not
+    shard with parameter parity; exact mode is one GPU (or independent replicas).  This is
+    the throughput mode the north star names next to it: rank r owns the users
+    ``[lo[r], lo[r+1])`` -- their rows of P / b_u are written by nobody else -- and holds a
+    replica of Q / b_i.  Per batch it runs the EXACT sequential SGD over the batch's
+    examples of its own users, in batch order, against its replica; then the replicas'
+    changes to Q / b_i are summed (all-reduce of the deltas) and every replica continues
+    from ``Q_before + sum of deltas``.  Examples of different ranks that share an item no
+    longer see each other's update inside a batch: results match the reference at the loss /
+    ranking level, not to 1e-5 on the parameters.  With one rank nothing is exchanged and
+    the result IS the reference's.
+
+    sgd_fn(it, positions)   exact sequential SGD over the given batch positions (ascending)
+    delta_fn() -> tensor    replica's Q / b_i minus their values after the last merge
+    merge_fn(total)         Q / b_i := values after the last merge + total
+    all_reduce(tensor)      in-place SUM over ranks
+    """
+
+    def __init__(self, world: int, rank: int, n_users: int, sgd_fn: Callable, delta_fn: Callable,
+                 merge_fn: Callable, all_reduce: Callable):
+        self.world, self.rank = world, rank
+        self.lo = user_ranges(n_users, world)
+        self.sgd_fn, self.delta_fn, self.merge_fn, self.all_reduce = sgd_fn, delta_fn, merge_fn, all_reduce
+
+    def mine(self, users):
+        """Batch positions (ascending) of the examples whose user this rank owns."""
+        import numpy as np
+
+        users = np.asarray(users)
+        return np.flatnonzero((users >= self.lo[self.rank]) & (users < self.lo[self.rank + 1]))
+
+    def step(self, it: int, batch_users) -> None:
+        self.sgd_fn(it, self.mine(batch_users))
+        if self.world > 1:
+            d = self.delta_fn()
+            self.all_reduce(d)
+            self.merge_fn(d)
+
+
+def hip_mf_partition_worker(rt, model, train: dict, world: int, rank: int, all_reduce=None,
+                            stage_host: bool = False):
+    """Bind ``MfUserPartitionStep`` to the HIP kernels for ``model`` (a
+    ``LogisticMatrixFactorization``) and the training log ``train``.  Returns
+    ``(step, finish)``: ``step.step(it, users_of_batch)`` with the batch's row ids in
+    ``step.batch_rows(it)``; ``finish()`` gathers the owners' P / b_u rows so that every rank
+    holds the whole model."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from . import _lib
+    from .mf import DevicePairs
+    from .runtime import mf_schedule_ex, sample_batches
+
+    tr = DevicePairs(rt, train["features"])
+    h_y = np.ascontiguousarray(train["labels"], dtype=np.float64)
+    h_p = np.ascontiguousarray(train["pscores"], dtype=np.float64)
+    k, B = model.n_factors, model.batch_size
+    model.b = float(np.mean(train["labels"]))
+    params = (model.P.dev.data_ptr(), model.Q.dev.data_ptr(), model.b_u.dev.data_ptr(),
+              model.b_i.dev.data_ptr())
+    cache_cap = int(min(1024, (32 << 10) // ((k + 2) * 8)))
+    nq, ni = model.n_items * k, model.n_items
+    sync = torch.cat([model.Q.dev.reshape(-1), model.b_i.dev.reshape(-1)]).clone()
+    delta = torch.empty_like(sync)
+    keep = []
+    ids = {}
+
+    def batch_rows(it: int) -> np.ndarray:
+        if it not in ids:
+            ids.clear()
+            ids[it] = sample_batches(tr.n, B, it, 1)[0]
+        return ids[it]
+
+    def sgd_fn(it: int, positions: np.ndarray) -> None:
+        if positions.size == 0:
+            return
+        rows = batch_rows(it)[positions]
+        ex, level_ptr, cache_items = mf_schedule_ex(tr.h_users[rows], tr.h_items[rows], h_y[rows], h_p[rows],
+                                                    model.n_users, model.n_items, cache_cap)
+        d_ex, d_lptr = rt.upload(ex.view(np.uint8)), rt.upload(level_ptr)
+        d_cache = rt.upload(cache_items if cache_items.size else np.zeros(1, np.int32))
+        keep.append((d_ex, d_lptr, d_cache))
+        if len(keep) > 32:
+            rt.sync()
+            del keep[:-1]
+        _lib.check(rt.lib.rfm_mf_sgd_levels_ex(
+            rt.ctx, d_ex.data_ptr(), level_ptr.ctypes.data, d_lptr.data_ptr(), len(level_ptr) - 1,
+            d_cache.data_ptr(), int(cache_items.size), *params, float(model.b), k, float(model.lr),
+            float(model.reg)))
+
+    def delta_fn():
+        _lib.check(rt.lib.rfm_mf_delta(rt.ctx, params[1], sync.data_ptr(), delta.data_ptr(), nq))
+        _lib.check(rt.lib.rfm_mf_delta(rt.ctx, params[3], sync.data_ptr() + nq * 8, delta.data_ptr() + nq * 8, ni))
+        return delta
+
+    def merge_fn(total) -> None:
+        _lib.check(rt.lib.rfm_mf_merge(rt.ctx, params[1], sync.data_ptr(), total.data_ptr(), nq))
+        _lib.check(rt.lib.rfm_mf_merge(rt.ctx, params[3], sync.data_ptr() + nq * 8, total.data_ptr() + nq * 8, ni))
+
+    def default_all_reduce(t) -> None:
+        if stage_host:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    step = MfUserPartitionStep(world, rank, model.n_users, sgd_fn, delta_fn, merge_fn,
+                               all_reduce or default_all_reduce)
+    step.batch_rows = batch_rows
+    step.users_of = lambda it: tr.h_users[batch_rows(it)]
+
+    def finish() -> None:
+        rt.sync()
+        if world == 1:
+            return
+        lo = step.lo
+        for r in range(world):
+            for t, width in ((model.P.dev, k), (model.b_u.dev, 1)):
+                part = t.reshape(-1)[lo[r] * width: lo[r + 1] * width]
+                if part.numel() == 0:
+                    continue
+                wire = part.cpu() if stage_host else part
+                dist.broadcast(wire, src=r)
+                if stage_host:
+                    part.copy_(wire)
+        rt.sync()
+
+    return step, finish

@@ -333,3 +333,65 @@ def test_touched_row_exchange_matches_single_gpu_step(tmp_path, world):
         np.testing.assert_array_equal(outs[0]["w"], o["w"])
         np.testing.assert_array_equal(outs[0]["w0"], o["w0"])
     plan.close()
+
+
+# ---------------------------------------------------------------------------
+# MF user-range partition on the HIP kernels
+# ---------------------------------------------------------------------------
+MF_KW = dict(n_factors=8, lr=0.02, reg=0.5, seed=12345, n_users=290, n_items=300)
+MF_EPOCHS, MF_BATCH = 4, 500
+
+
+def _mf_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    import relevance_factorizationmachine_amd as pkg
+    from relevance_factorizationmachine_amd.dist import hip_mf_partition_worker
+    from relevance_factorizationmachine_amd.runtime import Runtime
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        train, _ = synth.make_log("coat", "MF", "IPS", seed=0)
+        rt = Runtime.get(0)
+        model = pkg.LogisticMatrixFactorization(estimator="IPS", n_epochs=MF_EPOCHS, batch_size=MF_BATCH, **MF_KW)
+        step, finish = hip_mf_partition_worker(rt, model, train, world, rank, stage_host=True)
+        for it in range(MF_EPOCHS):
+            step.step(it, step.users_of(it))
+        finish()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), P=model.P(), Q=model.Q(), bu=model.b_u(), bi=model.b_i())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_mf_user_partition_on_the_device(tmp_path, world):
+    """The partitioned MF mode with the HIP kernels (ranks share the one GPU, host-staged
+    gloo) against a NumPy simulation of the same partition; one rank = the exact fit."""
+    import torch.multiprocessing as mp
+    from oracle import cpu_ref
+    from relevance_factorizationmachine_amd.dist import user_ranges
+
+    mp.spawn(_mf_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    train, _ = synth.make_log("coat", "MF", "IPS", seed=0)
+    X, y, p = train["features"], train["labels"], train["pscores"]
+    P, Q, bu, bi = cpu_ref.mf_init(MF_KW["seed"], MF_KW["n_users"], MF_KW["n_items"], MF_KW["n_factors"])
+    b, lo = float(np.mean(y)), user_ranges(MF_KW["n_users"], world)
+    for it in range(MF_EPOCHS):
+        rows = cpu_ref.batch_ids(X.shape[0], MF_BATCH, it)
+        users = X[rows, 0]
+        dQ, dbi = np.zeros_like(Q), np.zeros_like(bi)
+        for r in range(world):
+            mine = rows[(users >= lo[r]) & (users < lo[r + 1])]
+            Qr, bir = Q.copy(), bi.copy()
+            cpu_ref.mf_sgd_batch(X[mine], y[mine], p[mine], P, Qr, bu, bir, b, MF_KW["lr"], MF_KW["reg"])
+            dQ += Qr - Q
+            dbi += bir - bi
+        Q, bi = (Q + dQ, bi + dbi) if world > 1 else (Qr, bir)
+    outs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for o in outs:
+        for name, want in (("P", P), ("Q", Q), ("bu", bu), ("bi", bi)):
+            assert rel_err(o[name], want) < 1e-9, name
+    for o in outs[1:]:
+        np.testing.assert_array_equal(outs[0]["Q"], o["Q"])
+        np.testing.assert_array_equal(outs[0]["P"], o["P"])

@@ -399,6 +399,36 @@ int32_t rfm_topk_users(rfm_ctx* ctx, const double* d_scores, const int32_t* d_se
                        const int32_t* d_items, int32_t n_segments, int32_t k, int32_t* d_out_pos,
                        int32_t* d_out_flags);
 
+/* ---- CSR assembly -------------------------------------------
+ * The step before the training path: the FM design matrix of the reference's loaders
+ * -- one-hot user (+) one-hot item (+) per-interaction columns (+) the user's feature row
+ * (+) the item's feature row, hstack'ed (utils/dataloader/kuairec/_feature.py:54-84,
+ * 201-207; coat/_preparer.py:154-168) -- and the row selections made from it
+ * (features[indices]: kuairec/_preparer.py:117-136, loader.py:104-115).  Output row r
+ * is the concatenation, in segment order, of
+ *   kind 0: the single entry (col_offset + d_ids[r], 1.0)          -- a one-hot of an id
+ *   kind 1: row d_ids[r] (d_ids == NULL: row r) of a CSR block, its columns shifted by
+ *           col_offset                            -- a feature table gathered by id
+ * n_block_rows = rows of the block (kind 1) / size of the one-hot (kind 0); an id outside
+ * it is RFM_ERR_BAD_ARG.  Blocks use the ABI's dtypes (indptr int64, indices int32,
+ * values float64); stored zeros are kept as they are.  Call rfm_csr_assemble_count (fills
+ * d_out_indptr[n_rows + 1], returns the number of entries on the host -- it synchronises),
+ * allocate indices / values, then rfm_csr_assemble_fill. */
+typedef struct rfm_csr_segment {
+  int32_t kind;
+  const int32_t* d_ids;
+  const int64_t* d_indptr;
+  const int32_t* d_indices;
+  const double* d_values;
+  int64_t col_offset;
+  int64_t n_block_rows;
+} rfm_csr_segment;
+int32_t rfm_csr_assemble_count(rfm_ctx* ctx, const rfm_csr_segment* h_segments, int32_t n_segments,
+                               int64_t n_rows, int64_t* d_out_indptr, int64_t* h_out_nnz);
+int32_t rfm_csr_assemble_fill(rfm_ctx* ctx, const rfm_csr_segment* h_segments, int32_t n_segments,
+                              int64_t n_rows, const int64_t* d_indptr, int32_t* d_out_indices,
+                              double* d_out_values);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 # RFM_LIB_PATH: load another build of the same ABI (timing experiments under profiles/)
 LIB_PATH = os.environ.get("RFM_LIB_PATH") or os.path.join(PKG_DIR, "librfm_hip.so")
-SOURCES = ["rfm_capi.hip", "rfm_fm.hip", "rfm_fm_plan.hip", "rfm_mf.hip", "rfm_eval.hip", "rfm_host.cpp", "rfm_comm.cpp"]
+SOURCES = ["rfm_capi.hip", "rfm_fm.hip", "rfm_fm_plan.hip", "rfm_mf.hip", "rfm_eval.hip", "rfm_csr.hip", "rfm_host.cpp", "rfm_comm.cpp"]
 HEADERS = [os.path.join(CSRC, "rfm_common.h"), os.path.join(CSRC, "rfm_fm_kernels.hpp"),
            os.path.join(CSRC, "rfm_fm_rows.hpp"), os.path.join(CSRC, "rfm_fm_plan.h"),
            os.path.join(CSRC, "rfm_fm_records.h"),
@@ -118,8 +118,20 @@ SIGNATURES = {
     "rfm_mf_sgd_hogwild": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _i32, _f64,
                            _f64],
     "rfm_val_dcg": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
+    "rfm_csr_assemble_count": [_vp, _vp, _i32, _i64, _vp, _vp],
+    "rfm_csr_assemble_fill": [_vp, _vp, _i32, _i64, _vp, _vp, _vp],
     "rfm_topk_users": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
 }
+
+
+
+class CsrSegment(C.Structure):
+    """``rfm_csr_segment`` of include/rfm_hip.h."""
+
+    _fields_ = [("kind", C.c_int32), ("d_ids", C.c_void_p), ("d_indptr", C.c_void_p),
+                ("d_indices", C.c_void_p), ("d_values", C.c_void_p), ("col_offset", C.c_int64),
+                ("n_block_rows", C.c_int64)]
+
 
 _lib = None
 

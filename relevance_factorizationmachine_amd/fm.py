@@ -122,10 +122,11 @@ class FactorizationMachines(PointwiseBaseRecommender):
         # host chunk by chunk while the GPU trains on the chunk before
         id_stream = BatchIdStream(rt, n_rows, self.batch_size, self.n_epochs)
 
-        tr = DeviceCSR(rt, X)
+        # a log that is already in HBM (features.assemble / load_csr_to_device) is used as it is
+        tr = X if isinstance(X, DeviceCSR) else DeviceCSR(rt, X)
         y = rt.upload(np.asarray(train["labels"]), dtype=np.float64)
         p = rt.upload(np.asarray(train["pscores"]), dtype=np.float64)
-        va = DeviceCSR(rt, val["features"])
+        va = val["features"] if isinstance(val["features"], DeviceCSR) else DeviceCSR(rt, val["features"])
         vy = rt.upload(np.asarray(val["labels"]), dtype=np.float64)
         vp = rt.upload(np.asarray(val["pscores"]), dtype=np.float64)
         plan = FmPlan(rt, tr, y, p, self.n_factors, self.batch_size, self.hot_min_count)
@@ -200,7 +201,7 @@ class FactorizationMachines(PointwiseBaseRecommender):
         rt = self._rt
         if X.shape[1] != self.n_features:
             raise ValueError(f"X has {X.shape[1]} columns, model has {self.n_features}")
-        dev = self._csr_cache.get(X)
+        dev = X if isinstance(X, DeviceCSR) else self._csr_cache.get(X)
         n = dev.shape[0]
         out = rt.empty((n,), self.w.dev.dtype)
         _lib.check(rt.lib.rfm_fm_forward(

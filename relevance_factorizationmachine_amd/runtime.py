@@ -98,6 +98,28 @@ class DeviceCSR:
         self.values = rt.upload(self.h_values if self.nnz else np.zeros(1, np.float64))
 
 
+def _device_csr_from_device(cls, rt: Runtime, shape, nnz: int, indptr, indices, values) -> "DeviceCSR":
+    """A ``DeviceCSR`` around arrays that are already in HBM (int64 / int32 / float64)."""
+    self = cls.__new__(cls)
+    self.shape, self.nnz = (int(shape[0]), int(shape[1])), int(nnz)
+    self.indptr, self.indices, self.values = indptr, indices, values
+    self.h_indptr = self.h_indices = self.h_values = None
+    return self
+
+
+def _device_csr_to_scipy(self):
+    """Download as ``scipy.sparse.csr_matrix`` (float64 data, int32 indices)."""
+    from scipy.sparse import csr_matrix
+
+    indptr = self.indptr.cpu().numpy()
+    return csr_matrix((self.values.cpu().numpy()[: self.nnz], self.indices.cpu().numpy()[: self.nnz],
+                       indptr.astype(np.int32) if self.nnz < 2 ** 31 else indptr), shape=self.shape)
+
+
+DeviceCSR.from_device = classmethod(_device_csr_from_device)
+DeviceCSR.to_scipy = _device_csr_to_scipy
+
+
 class CsrCache:
     """Remembers the device copy of the last few host matrices handed to
     predict() (the evaluator hook passes the same object every iteration)."""

@@ -225,7 +225,8 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   f.k = k;
   f.out_err = plan->err.as<double>();
   f.out_Q = plan->Q.as<double>();
-  f.slot_t = plan->slot_t.as<int32_t>();
+  f.slot_mark = plan->slot_t.as<SlotMark>();
+  f.slot_bits = plan->slot_bits.as<unsigned long long>();
   f.n_hot = plan->n_hot;
   f.hot_slab = plan->hot_slab.as<double>();
   f.err_partial = plan->err_partial.as<double>();
@@ -247,73 +248,73 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   const double stamp = double(++plan->step);
   {
     ConsArgs c{};
-    c.win = plan->win.as<WinInfo>();
-    c.n_win = plan->n_win;
-    c.n_slots = int32_t(plan->n_slots);
-    c.slot_t = plan->slot_t.as<int32_t>();
+    c.tasks = plan->tasks.as<TaskRec>();
+    c.task_words = plan->task_words;
+    c.slot_bits = plan->slot_bits.as<unsigned long long>();
+    c.slot_mark = plan->slot_t.as<SlotMark>();
     c.slots = plan->slots.as<SlotRec>();
-    c.err = plan->err.as<double>();
     c.Q = plan->Q.as<double>();
     c.k = k;
     c.n = plan->n_features;
+    c.w0 = d_w0;
     c.V = d_V;
     c.w = d_w;
     c.lr = lr;
-    c.carries = plan->carries.as<double>();
+    c.parts = plan->parts.as<double>();
     c.stamp = stamp;
     c.grad = d_grad;
     c.touch = d_touch;
     c.touch_id = touch_id;
-    const int wpb = (kBlock / kWave) * (kWave / s.lpr);  // one window per lane group
-    c.nb_win = (plan->n_win + wpb - 1) / wpb;
+    c.nb_tasks = plan->n_task_blocks;  // one task per lane group
     c.n_hot = plan->n_hot;
+    c.hot_cols = plan->hot_cols.as<int32_t>();
     c.hot_slab = plan->hot_slab.as<double>();
     c.n_slabs = geom.grid;
-    c.hot_part = plan->hot_part.as<double>();
-    const int grid = c.nb_win + plan->n_hot * kHotParts;  // windows, then the hot columns' parts
+    c.err_partial = plan->err_partial.as<double>();
+    const int grid = c.nb_tasks + c.n_hot + 1;  // tasks, then the hot columns, then w0
+    // LDS: the groups' lists + parked records + head rows, or the hot workgroups' scratch
+    const int gpb = kBlock / s.lpr;
+    const int win = s.lpr >= 32 ? 64 : 4 * s.lpr;  // WinShape<LPR>::WIN
+    const size_t lds = std::max<size_t>(size_t(gpb) * size_t(win) * (sizeof(WinRec) + 8) +
+                                            size_t(gpb) * size_t(k + 3) * 8,
+                                        size_t(kBlock + 1024 + 2) * 8);
 #ifdef RFM_ABLATE
     if (!(f.ablate & 128))
 #endif
-    if (grid > 0) {
+    {
 #define RFM_CALL_CONS(L, Vv, N) \
-  hipLaunchKernelGGL((fm_consume_kernel<L, Vv, N>), dim3(grid), dim3(kBlock), 0, ctx->stream, c)
+  hipLaunchKernelGGL((fm_consume_kernel<L, Vv, N>), dim3(grid), dim3(kBlock), lds, ctx->stream, c)
       RFM_FOR_SHAPE(s, RFM_CALL_CONS);
 #undef RFM_CALL_CONS
       RFM_HIP_CHECK(hipGetLastError());
     }
   }
   ctx->prof_mark();
-  FinArgs fa{};
-  fa.cross = plan->cross.as<CrossCol>();
-  fa.n_cross_short = plan->n_cross_short;
-  fa.n_cross_long = plan->n_cross_long;
-  fa.carry_idx = plan->carry_idx.as<int32_t>();
-  fa.carries = plan->carries.as<double>();
-  fa.stamp = stamp;
-  fa.hot_cols = plan->hot_cols.as<int32_t>();
-  fa.n_hot = plan->n_hot;
-  fa.hot_part = plan->hot_part.as<double>();
-  fa.n_slabs = geom.grid;
-  fa.err_partial = plan->err_partial.as<double>();
-  fa.k = k;
-  fa.n = plan->n_features;
-  fa.w0 = d_w0;
-  fa.w = d_w;
-  fa.V = d_V;
-  fa.lr = lr;
-  fa.grad = d_grad;
-  fa.touch = d_touch;
-  fa.touch_id = touch_id;
-  {
+  // columns cut into several tasks (none on most plans): their partial rows
+  if (plan->n_split_short + plan->n_split_long > 0) {
+    FinArgs fa{};
+    fa.split = plan->split.as<SplitCol>();
+    fa.n_split_short = plan->n_split_short;
+    fa.n_split_long = plan->n_split_long;
+    fa.parts = plan->parts.as<double>();
+    fa.stamp = stamp;
+    fa.k = k;
+    fa.n = plan->n_features;
+    fa.w = d_w;
+    fa.V = d_V;
+    fa.lr = lr;
+    fa.grad = d_grad;
+    fa.touch = d_touch;
+    fa.touch_id = touch_id;
     const int gpb = kBlock / s.lpr;
-    const int nb_cross = (plan->n_hot + plan->n_cross_short + gpb - 1) / gpb;
-    const int grid = nb_cross + plan->n_cross_long + 1;
+    const int nb_short = (plan->n_split_short + gpb - 1) / gpb;
+    const int grid = nb_short + plan->n_split_long;
 #ifdef RFM_ABLATE
     if (f.ablate & 256) return;
 #endif
 #define RFM_CALL_FIN(L, Vv, N)                                                                 \
   hipLaunchKernelGGL((fm_finalize_kernel<L, Vv, N>), dim3(grid), dim3(kBlock), 0, ctx->stream, \
-                     fa, nb_cross)
+                     fa, nb_short)
     RFM_FOR_SHAPE(s, RFM_CALL_FIN);
 #undef RFM_CALL_FIN
     RFM_HIP_CHECK(hipGetLastError());

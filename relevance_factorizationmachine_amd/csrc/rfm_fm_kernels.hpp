@@ -125,7 +125,8 @@ struct FwdArgs {
   double* out_pred;      // nullable
   double* out_err;       // nullable
   double* out_Q;         // nullable [n_rows][k]
-  int32_t* slot_t;       // nullable: mark slot_t[slot] = t for sparse-class entries
+  SlotMark* slot_mark;   // nullable: leave {t, residual} at the slot of every sparse-class entry ...
+  unsigned long long* slot_bits;  // ... and set the slot's bit (what fm_consume_kernel scans)
   int32_t n_hot;         // hot columns (training step only)
   double* hot_slab;      // [n_hot][gridDim.x][k+2]
   double* err_partial;   // nullable: [gridDim.x] per-workgroup sums of the residual (for w0)
@@ -276,8 +277,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
 #pragma unroll
       for (int i = 0; i < R; ++i) {
         lin[i] += a.w[e[i].col] * e[i].x;
-        if (REC && a.slot_t && e[i].slot >= 0 && pb + l < len[i] && RFM_KEEP(a, 1))
-          a.slot_t[e[i].slot] = int32_t(t[i]);
         ebuf[i * LPR + l] = e[i];
       }
       const int cnt = (maxlen - pb) < LPR ? (maxlen - pb) : LPR;
@@ -352,18 +351,35 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
       }
     }
 
-    if (REC && H > 0 && RFM_KEEP(a, 32)) {
-      // hot entries: err * x * [q, 1, x] into the workgroup's LDS sums.  A single
-      // round (rows of at most LPR entries) still has its entries parked in LDS.
+    if (REC && (a.slot_mark || (H > 0 && RFM_KEEP(a, 32)))) {
+      // after the residual is known: marks of the sparse-class entries, and the hot
+      // entries' err * x * [q, 1, x] into the workgroup's LDS sums.  A single round (rows
+      // of at most LPR entries) still has its entries parked in LDS.
       for (int pb = 0; pb < maxlen; pb += LPR) {
-        if (maxlen > LPR) {
+        Entry em[R];
 #pragma unroll
-          for (int i = 0; i < R; ++i) {
-            Entry e = a.ent[len[i] > 0 ? p0[i] + min(pb + l, len[i] - 1) : 0];
-            if (pb + l >= len[i]) e = Entry{0, 0, 0.0};
-            ebuf[i * LPR + l] = e;
+        for (int i = 0; i < R; ++i) {
+          if (maxlen > LPR) {
+            em[i] = a.ent[len[i] > 0 ? p0[i] + min(pb + l, len[i] - 1) : 0];
+            if (pb + l >= len[i]) em[i] = Entry{0, 0, 0.0};
+            ebuf[i * LPR + l] = em[i];
+          } else {
+            em[i] = ebuf[i * LPR + l];
           }
         }
+        if (a.slot_mark && RFM_KEEP(a, 1)) {
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            if (pb + l < len[i] && em[i].slot >= 0) {
+              // the row's batch position and residual at the entry's slot (plain store: the
+              // row ids of a step are distinct), and the slot's bit in the map the gradient
+              // launch scans (no-return atomic)
+              a.slot_mark[em[i].slot] = SlotMark{int32_t(t[i]), 0, err[i]};
+              atomicOr(a.slot_bits + (em[i].slot >> 6), 1ull << (em[i].slot & 63));
+            }
+          }
+        }
+        if (!(H > 0 && RFM_KEEP(a, 32))) continue;
         const int cnt = (maxlen - pb) < LPR ? (maxlen - pb) : LPR;
         // the lane groups of a wave start at different entries: rows of one log
         // tend to hold the same hot column at the same position, and adds to one
@@ -504,10 +520,10 @@ __device__ inline void ordered_rows_sum(const double* base, int rows, int width,
   __syncthreads();
 }
 
-// Same for the stamped carry rows of one long crossing column: row r is
-// carries[idx[r]], valid iff its stamp is this step's.
-__device__ inline void ordered_carry_sum(const double* carries, const int32_t* idx, int rows,
-                                         int k, double stamp, double* scratch, double* tot) {
+// Same for the stamped partial rows of one split column: rows first .. first+rows-1 of
+// `parts`, each valid iff its stamp is this step's.
+__device__ inline void ordered_part_sum(const double* parts, int first, int rows, int k,
+                                        double stamp, double* scratch, double* tot) {
   constexpr int U = 8;
   const int width = k + 2;
   const int fw = width < kBlock ? width : kBlock;
@@ -523,7 +539,7 @@ __device__ inline void ordered_carry_sum(const double* carries, const int32_t* i
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int rr = r + u * nsg;
-          row[u] = carries + int64_t(idx[rr < rows ? rr : r]) * (k + 3);
+          row[u] = parts + int64_t(first + (rr < rows ? rr : r)) * (k + 3);
         }
         double v[U], st[U];
 #pragma unroll
@@ -547,21 +563,10 @@ __device__ inline void ordered_carry_sum(const double* carries, const int32_t* i
   __syncthreads();
 }
 
-// Part `part` of hot column h: slabs [part*n/kHotParts, (part+1)*n/kHotParts) summed
-// in block order into hot_part[h][part][0..k+2).  Whole workgroup.
-__device__ inline void hot_part_block(int h, int part, const double* hot_slab, int n_slabs,
-                                      int k, double* hot_part, double* scratch, double* tot) {
-  const int lo = int(int64_t(part) * n_slabs / kHotParts);
-  const int hi = int(int64_t(part + 1) * n_slabs / kHotParts);
-  ordered_rows_sum(hot_slab + (int64_t(h) * n_slabs + lo) * (k + 2), hi - lo, k + 2, scratch, tot);
-  double* out = hot_part + (int64_t(h) * kHotParts + part) * (k + 2);
-  for (int f = threadIdx.x; f < k + 2; f += kBlock) out[f] = tot[f];
-}
-
 // ---------------------------------------------------------------------------
-// 2. sparse-class gradient + update: one fixed window of slots per lane group
+// 2. sparse-class gradient + update (tasks of whole columns), hot columns, w0
 // ---------------------------------------------------------------------------
-struct WinRec {  // a marked slot of the window being processed, parked in LDS, 24 B
+struct WinRec {  // a marked slot of the word being processed, parked in LDS, 24 B
   int32_t t;     // batch position of the slot's row
   int32_t col;   // feature column
   double coef;   // err_t * x
@@ -569,30 +574,31 @@ struct WinRec {  // a marked slot of the window being processed, parked in LDS, 
 };
 
 struct ConsArgs {
-  const WinInfo* win;
-  int32_t n_win;
-  int32_t n_slots;
-  int32_t* slot_t;
+  const TaskRec* tasks;  // [nb_tasks * tasks per workgroup]
+  int32_t task_words;    // 64-slot words of the slot bitmap per task
+  unsigned long long* slot_bits;  // one bit per slot: set by the forward, cleared here
+  const SlotMark* slot_mark;      // {batch position, residual} of a marked slot's row
   const SlotRec* slots;
-  const double* err;
   const double* Q;
   int32_t k;
   int64_t n;        // features
+  double* w0;
   double* V;        // apply mode: updated in place; grad mode: read only
   double* w;
   double lr;
-  double* carries;  // [n_win*2][k+3]: M[0..k), sum coef, sum coef*x, step stamp
-  double stamp;     // id of this step (a carry row is valid iff its stamp matches)
+  double* parts;    // [n_parts][k+3]: M[0..k), sum coef, sum coef*x, step stamp (split columns)
+  double stamp;     // id of this step (a partial row is valid iff its stamp matches)
   double* grad;     // nullable: grad mode -> [G_V | g_w | g_w0]
   int32_t* touch;   // nullable (grad mode): touch[col] = touch_id for every column written
   int32_t touch_id;
-  // hot columns ride in the same launch: the workgroups after the windows reduce
-  // the forward's slabs (independent of the sparse class, so the two overlap)
-  int32_t nb_win;   // workgroups that process windows
+  // the hot columns and w0 ride in the same launch: the workgroups after the tasks reduce
+  // the forward's slabs / residual sums (independent of the sparse class, so they overlap)
+  int32_t nb_tasks;  // workgroups that process tasks
   int32_t n_hot;
+  const int32_t* hot_cols;
   const double* hot_slab;
   int32_t n_slabs;
-  double* hot_part;  // [n_hot][kHotParts][k+2] partial sums out (fm_finalize_kernel adds them)
+  const double* err_partial;  // [n_slabs] per-workgroup sums of the residual
 };
 
 template <int VEC, int NC>
@@ -643,195 +649,333 @@ __device__ inline void apply_column(const ColAcc<VEC, NC>& acc, const Pack<VEC> 
   }
 }
 
-// slots a lane group covers: PLANES pieces of LPR consecutive slots
+// The same from a whole workgroup, sums in LDS: tot[0..k) = M, tot[k] = sum coef,
+// tot[k+1] = sum coef*x.
+__device__ inline void apply_column_block(const double* tot, int32_t col, double* V, double* w,
+                                          double* grad, int64_t n, int k, double lr,
+                                          int32_t* touch, int32_t touch_id) {
+  const double gw = tot[k], d = tot[k + 1];
+  for (int f = threadIdx.x; f < k; f += kBlock) {
+    const int64_t at = int64_t(col) * k + f;
+    if (grad)
+      grad[at] = d * V[at] - tot[f];
+    else
+      V[at] += lr * (tot[f] - d * V[at]);
+  }
+  if (threadIdx.x == 0) {
+    if (grad) {
+      grad[n * k + col] = -gw;
+      if (touch) touch[col] = touch_id;
+    } else {
+      w[col] += lr * gw;
+    }
+  }
+}
+
+// slots a lane group handles per pass over a 64-slot word of the bitmap: PLANES pieces of
+// LPR consecutive slots
 template <int LPR>
 struct WinShape {
   static constexpr int PLANES = LPR >= 64 ? 1 : (LPR == 32 ? 2 : 4);
-  static constexpr int WIN = PLANES * LPR;
+  static constexpr int WIN = PLANES * LPR;  // 64 for LPR >= 16; 16 / 32 for LPR = 4 / 8
 };
 
-// A finished column of a window: updated in place when it lies wholly inside the
-// window, else left as a stamped carry row for fm_finalize_kernel.
-// (A plain function, not a lambda: a closure object would live in scratch memory.)
-template <int LPR, int VEC, int NC>
-__device__ __forceinline__ void emit_column(const ColAcc<VEC, NC>& acc,
-                                            const Pack<VEC> (&vold)[NC], int32_t cur,
-                                            const WinInfo& wi, int wid, const ConsArgs& a,
-                                            int l) {
-  const int k = a.k;
-  const bool carry0 = cur == wi.first_col && (wi.flags & 1);
-  const bool carry1 = !carry0 && cur == wi.last_col && (wi.flags & 2);
-  if (carry0 || carry1) {
-    double* row = a.carries + (int64_t(wid) * 2 + (carry1 ? 1 : 0)) * (k + 3);
+// inclusive prefix sum over the LPR lanes of a lane group
+template <int LPR>
+__device__ inline int group_scan(int v, int l) {
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int f = (c * LPR + l) * VEC;
-      if (f < k) {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) row[f + v] = acc.m[c][v];
-      }
-    }
-    if (l == 0) {
-      row[k] = acc.gw;
-      row[k + 1] = acc.d;
-      row[k + 2] = a.stamp;
-    }
-  } else {
-    apply_column<LPR, VEC, NC>(acc, vold, cur, a.V, a.w, a.grad, a.n, k, a.lr, l, a.touch,
-                               a.touch_id);
+  for (int o = 1; o < LPR; o <<= 1) {
+    const int up = __shfl_up(v, o, LPR);
+    if (l >= o) v += up;
   }
+  return v;
 }
 
-// One window of WIN consecutive slots per LANE GROUP (64/LPR windows per wave):
-// every group does the same short chain -- marks -> per-slot records of the
-// marked slots -> Q rows (four gathers in flight) -> update -- and no group
-// walks a long list, so the launch is one flat wave of independent work.  The
-// marked slots' err*x*[Q[t,:], 1, x] are added strictly in slot order.  A column
-// that lies wholly inside the window is updated here (this group is its only
-// writer); a column that crosses a window border leaves a stamped partial
-// ("carry") that fm_finalize_kernel adds up in window order.
+// One TASK per lane group: `task_words` 64-slot words of the slot view, the same number for
+// every task of a plan (chosen so that a task expects a handful of marked slots), so the
+// task's bitmap words are the kernel's FIRST load -- nothing has to be looked up before
+// them.  Whole columns are packed into the tasks in column order; a column may run over
+// several consecutive tasks, but never over the edge of a workgroup's tasks unless it is
+// longer than all of them together.  The group lists the task's marked slots, in slot
+// order, in LDS, then runs the chain ONCE: the marked slots' records and marks (parked in
+// LDS) -> Q rows and V rows (eight gathers in flight) -> err*x*[Q[t,:], 1, x] accumulated
+// strictly in slot order.  A column that lies inside the task is updated in place -- this
+// group is its only writer.  For a column that continues from the previous task the sums
+// go to LDS (`head` row of the group); the group in whose task such a column STARTS owns
+// it: after a workgroup barrier it adds the followers' head rows in task (= slot) order to
+// its own and updates the column.  Only a column longer than a whole workgroup's tasks
+// leaves partial rows in memory (one per workgroup) for fm_finalize_kernel.  The work of a
+// launch follows the batch (marked slots): an untouched task reads its bitmap words and
+// waits at the barrier.
+// (The lane groups of a wave run in lock step: ballots and shuffles are wave-wide.)
 template <int LPR, int VEC, int NC>
 __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
-  constexpr int GPW = kWave / LPR;
+  constexpr int GPB = kBlock / LPR;  // tasks of a workgroup
   constexpr int PLANES = WinShape<LPR>::PLANES;
-  constexpr int WIN = WinShape<LPR>::WIN;
-  constexpr int BATCH = 4;
-  constexpr unsigned long long GMASK = LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull);
-  // LDS: the windows' parked records, or (hot-column workgroups) reduction scratch
-  constexpr int kWrecBytes = (kBlock / LPR) * WIN * int(sizeof(WinRec));
+  constexpr int WIN = WinShape<LPR>::WIN;  // marked slots a group lists before it runs the chain
+  constexpr int BATCH = 4;                 // entries whose Q and V rows are in flight together
+  constexpr int TRIPS = kTaskTrips;        // bitmap words a lane loads (task_words <= TRIPS*LPR)
+  // LDS: per group the list of marked slots and their parked records, then the head rows; or
+  // (hot-column / w0 workgroups) reduction scratch
+  constexpr int kGroupBytes = WIN * (int(sizeof(WinRec)) + 8);
   constexpr int kHotBytes = (kBlock + 1024 + 2) * int(sizeof(double));
-  __shared__ double lds_raw[(kWrecBytes > kHotBytes ? kWrecBytes : kHotBytes) / 8];
-  // the hot-column workgroups come last in the grid (measured: first, they delay
-  // the windows and the launch takes 4 us longer); kHotParts of them per column
-  if (int(blockIdx.x) >= a.nb_win) {
-    const int hb = int(blockIdx.x) - a.nb_win;
-    hot_part_block(hb / kHotParts, hb % kHotParts, a.hot_slab, a.n_slabs, a.k, a.hot_part, lds_raw,
-                   lds_raw + kBlock);
+  extern __shared__ double lds_raw[];  // max(GPB * kGroupBytes + GPB * (k+3) * 8, kHotBytes)
+  const int k = a.k;
+  // the hot-column workgroups come last in the grid (measured: first, they delay the
+  // tasks and the launch takes longer)
+  if (int(blockIdx.x) >= a.nb_tasks) {
+    const int hb = int(blockIdx.x) - a.nb_tasks;
+    double* tot = lds_raw + kBlock;
+    if (hb < a.n_hot) {
+      // a hot column: the forward workgroups' slabs, in block order
+      ordered_rows_sum(a.hot_slab + int64_t(hb) * a.n_slabs * (k + 2), a.n_slabs, k + 2, lds_raw,
+                       tot);
+      apply_column_block(tot, a.hot_cols[hb], a.V, a.w, a.grad, a.n, k, a.lr, a.touch,
+                         a.touch_id);
+    } else {
+      // w0 from the forward workgroups' residual sums
+      double acc = 0.0;
+      for (int i = threadIdx.x; i < a.n_slabs; i += kBlock) acc += a.err_partial[i];
+      const double s = block_sum<kBlock>(acc, lds_raw);
+      if (threadIdx.x == 0) {
+        if (a.grad)
+          a.grad[a.n * k + a.n] = -s;
+        else
+          a.w0[0] += a.lr * s;
+      }
+    }
     return;
   }
-  const int wblock = int(blockIdx.x);
+  (void)kHotBytes;
   const int lane = threadIdx.x % kWave;
   const int l = lane % LPR;
-  const int g = lane / LPR;
-  const int wid = (wblock * (kBlock / kWave) + threadIdx.x / kWave) * GPW + g;
-  const bool have = wid < a.n_win;
-  const int32_t w0 = have ? wid * WIN : 0;
-  const int k = a.k;
-
-  // marks of the window and its static description (independent loads; slot_t
-  // and slots are padded by one window, so no clamp is needed)
-  int32_t tk[PLANES];
+  const int gb = threadIdx.x / LPR;  // group in the workgroup
+  const int task = int(blockIdx.x) * GPB + gb;
+  const int W = a.task_words;
+  const int32_t slot0 = task * W * 64;  // first slot of the task
+  // first loads: the task's bitmap words (one per lane and trip) and its description
+  unsigned long long wd[TRIPS];
 #pragma unroll
-  for (int pl = 0; pl < PLANES; ++pl) {
-    const int32_t s = w0 + pl * LPR + l;
-    const int32_t t = a.slot_t[s];
-    tk[pl] = (have && s < a.n_slots) ? t : -1;
+  for (int u = 0; u < TRIPS; ++u) {
+    const int idx = u * LPR + l;
+    wd[u] = idx < W ? a.slot_bits[int64_t(task) * W + idx] : 0ull;
   }
-  const WinInfo wi = a.win[have ? wid : 0];
-  unsigned long long M = 0ull;  // bit (pl*LPR + lane): slot order
+  const TaskRec tk = a.tasks[task];
 #pragma unroll
-  for (int pl = 0; pl < PLANES; ++pl) {
-    const unsigned long long m = (__ballot(tk[pl] >= 0) >> (g * LPR)) & GMASK;
-    M |= m << ((pl * LPR) & 63);
-  }
-  if (M == 0ull) return;
+  for (int u = 0; u < TRIPS; ++u)
+    if (wd[u]) a.slot_bits[int64_t(task) * W + u * LPR + l] = 0ull;  // consumed: cleared at once
 
-  // per-slot data of the whole window, loaded unconditionally so that the loads
-  // of the planes overlap; the marked slots' records are parked in LDS, indexed by
-  // their position in the window, and read back as broadcasts
-  WinRec* wrec = reinterpret_cast<WinRec*>(lds_raw) + (threadIdx.x / LPR) * WIN;
-  {
-    SlotRec sr[PLANES];
-    double ee[PLANES];
-#pragma unroll
-    for (int pl = 0; pl < PLANES; ++pl) {
-      // unmarked lanes read the window's first record: only the lines of marked
-      // slots are fetched (a batch marks a few percent of the log's slots)
-      sr[pl] = a.slots[tk[pl] >= 0 ? w0 + pl * LPR + l : w0];
-      ee[pl] = a.err[max(tk[pl], 0)];
-    }
-#pragma unroll
-    for (int pl = 0; pl < PLANES; ++pl) {
-      if (tk[pl] >= 0) {
-        a.slot_t[w0 + pl * LPR + l] = -1;
-        const double coef = ee[pl] * sr[pl].x;
-        wrec[pl * LPR + l] = WinRec{tk[pl], sr[pl].col, coef, coef * sr[pl].x};
-      }
-    }
-  }
+  char* gmem = reinterpret_cast<char*>(lds_raw) + gb * kGroupBytes;
+  WinRec* wrec = reinterpret_cast<WinRec*>(gmem);
+  int32_t* list = reinterpret_cast<int32_t*>(gmem + WIN * sizeof(WinRec));
+  double* heads = reinterpret_cast<double*>(reinterpret_cast<char*>(lds_raw) + GPB * kGroupBytes);
+  double* head = heads + gb * (k + 3);  // [0..k) M, [k] sum coef, [k+1] sum coef*x, [k+2] flags
 
+  const bool head_open = tk.flags & 1;  // first_col continues from the previous task
+  const bool tail_open = tk.flags & 2;  // last_col continues into the next task
   ColAcc<VEC, NC> acc;
   acc.clear();
-  Pack<VEC> vold[NC];  // V row of the column being accumulated, fetched when it starts
-  int32_t cur = -1;    // that column (uniform in the lane group)
+  Pack<VEC> vold[NC];   // V row of the column being accumulated
+  int32_t cur = -1;     // that column (uniform in the lane group)
+  int fill = 0;         // marked slots listed and not yet consumed (uniform in the lane group)
+  bool head_done = false;
 
-  while (M) {
-    int bsel[BATCH];
-    int nb = 0;
+  // a finished column: into the head row (continues from the previous task), or updated in
+  // place; the last column of a tail-open task stays in `acc` for the combine below
+  const auto finish = [&]() {
+    if (head_open && cur == tk.first_col) {
 #pragma unroll
-    for (int u = 0; u < BATCH; ++u) {
-      bsel[u] = u ? bsel[0] : 0;
-      if (M) {
-        bsel[u] = __ffsll((long long)M) - 1;
-        M &= M - 1;
-        ++nb;
+      for (int c = 0; c < NC; ++c) {
+        const int f = (c * LPR + l) * VEC;
+        if (f < k) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) head[f + v] = acc.m[c][v];
+        }
+      }
+      if (l == 0) {
+        head[k] = acc.gw;
+        head[k + 1] = acc.d;
+      }
+      head_done = true;
+    } else {
+      apply_column<LPR, VEC, NC>(acc, vold, cur, a.V, a.w, a.grad, a.n, k, a.lr, l, a.touch,
+                                 a.touch_id);
+    }
+  };
+
+  // the chain over the group's list of `fill` marked slots
+  const auto run_list = [&]() {
+    // records and marks of the listed slots, parked in LDS by list position
+    {
+      SlotRec sr[PLANES];
+      SlotMark mk[PLANES];
+#pragma unroll
+      for (int pl = 0; pl < PLANES; ++pl) {
+        const int e = pl * LPR + l;
+        const int32_t s = e < fill ? list[e] : slot0;
+        mk[pl] = a.slot_mark[s];
+        sr[pl] = a.slots[s];
+      }
+#pragma unroll
+      for (int pl = 0; pl < PLANES; ++pl) {
+        const int e = pl * LPR + l;
+        if (e < fill) {
+          const double coef = mk[pl].err * sr[pl].x;
+          wrec[e] = WinRec{mk[pl].t, sr[pl].col, coef, coef * sr[pl].x};
+        }
       }
     }
-    WinRec rec[BATCH];
-    Pack<VEC> qq[BATCH][NC];
+    // every group of the wave loops as long as any of them has entries left
+    int at = 0;
+    while (__ballot(at < fill)) {
+      const int nb = max(min(BATCH, fill - at), 0);
+      WinRec rec[BATCH];
+      Pack<VEC> qq[BATCH][NC], vv[BATCH][NC];
 #pragma unroll
-    for (int u = 0; u < BATCH; ++u) {
-      rec[u] = wrec[bsel[u]];
+      for (int u = 0; u < BATCH; ++u) {
+        rec[u] = wrec[u < nb ? at + u : 0];
+        if (u >= nb) {  // nothing there: any row of Q / V will do
+          rec[u].t = 0;
+          rec[u].col = 0;
+        }
+        // the entry's Q row, and the V row of its column in case the entry starts a new
+        // column: fetched together, so that a run of one-entry columns (one-hot users and
+        // items in a small batch) costs one round trip, not one per column
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+          const int f = (ch * LPR + l) * VEC;
+          qq[u][ch].load(a.Q + int64_t(rec[u].t) * k + (f < k ? f : 0));
+          vv[u][ch].load(a.V + int64_t(rec[u].col) * k + (f < k ? f : 0));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        if (u < nb) {
+          if (rec[u].col != cur) {
+            if (cur >= 0) finish();
+            acc.clear();
+            cur = rec[u].col;
+#pragma unroll
+            for (int ch = 0; ch < NC; ++ch) vold[ch] = vv[u][ch];
+          }
+#pragma unroll
+          for (int ch = 0; ch < NC; ++ch)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc.m[ch][v] += rec[u].coef * qq[u][ch].v[v];
+          acc.gw += rec[u].coef;
+          acc.d += rec[u].cx;
+        }
+      }
+      at += nb;
+    }
+    fill = 0;
+  };
+
+#pragma unroll
+  for (int u = 0; u < TRIPS; ++u) {
+    unsigned long long word = wd[u];
+    const int32_t s0 = slot0 + (u * LPR + l) * 64;  // first slot of this lane's word
+    // move the trip's marked slots into the list in lane (= slot) order, as many as the list
+    // has room for; when a group's list is full and it has marks left, every group of the
+    // wave runs the chain on what it has listed so far
+    while (__ballot(word != 0ull)) {
+      const int cnt = __popcll(word);
+      const int before = group_scan<LPR>(cnt, l) - cnt;  // marks of the group's earlier lanes
+      const int take = min(cnt, max(WIN - fill - before, 0));
+      int pos = fill + before;
+      for (int i = 0; i < take; ++i) {
+        list[pos++] = s0 + (__ffsll((long long)word) - 1);
+        word &= word - 1ull;
+      }
+      int added = take;
+#pragma unroll
+      for (int o = 1; o < LPR; o <<= 1) added += __shfl_xor(added, o, LPR);
+      fill += added;
+      if (__ballot(word != 0ull)) run_list();
+    }
+  }
+  if (__ballot(fill > 0)) run_list();
+
+  // ---- columns that run over several tasks of this workgroup -----------------------------
+  // the last column of a tail-open task is still in `acc` (if it got any entry here); a
+  // column that both comes in and goes on (the task lies inside it) counts as a head row
+  const bool through = head_open && tail_open && tk.first_col == tk.last_col;
+  // this group owns the combine of tk.last_col: the column starts (or, for a piece of a very
+  // long column, this workgroup's share of it starts) in this task
+  const bool own = (tail_open && !through) || tk.part >= 0;
+  bool own_acc = false;  // ... and holds entries of it in `acc`
+  if (cur >= 0) {
+    if (own && cur == tk.last_col) {
+      own_acc = true;
+    } else {
+      finish();
+    }
+  }
+  if (head_open && l == 0) head[k + 2] = (head_done ? 1.0 : 0.0) + (through ? 2.0 : 0.0);
+  if (!head_open && l == 0) head[k + 2] = 0.0;
+  __syncthreads();
+  if (own) {
+    if (!own_acc) {
+      acc.clear();
 #pragma unroll
       for (int ch = 0; ch < NC; ++ch) {
         const int f = (ch * LPR + l) * VEC;
-        qq[u][ch].load(a.Q + int64_t(rec[u].t) * k + (f < k ? f : 0));
+        vold[ch].load(a.V + int64_t(tk.last_col) * k + (f < k ? f : 0));
       }
     }
+    bool any = own_acc;
+    for (int g2 = gb + 1; g2 < GPB; ++g2) {
+      const double* h2 = heads + g2 * (k + 3);
+      const int fl = int(h2[k + 2]);
+      if (fl & 1) {
+        any = true;
 #pragma unroll
-    for (int u = 0; u < BATCH; ++u) {
-      if (u < nb) {
-        if (rec[u].col != cur) {
-          if (cur >= 0) emit_column<LPR, VEC, NC>(acc, vold, cur, wi, wid, a, l);
-          acc.clear();
-          cur = rec[u].col;
+        for (int ch = 0; ch < NC; ++ch) {
+          const int f = (ch * LPR + l) * VEC;
+          if (f < k) {
 #pragma unroll
-          for (int ch = 0; ch < NC; ++ch) {
-            const int f = (ch * LPR + l) * VEC;
-            vold[ch].load(a.V + int64_t(cur) * k + (f < k ? f : 0));
+            for (int v = 0; v < VEC; ++v) acc.m[ch][v] += h2[f + v];
           }
         }
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch)
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) acc.m[ch][v] += rec[u].coef * qq[u][ch].v[v];
-        acc.gw += rec[u].coef;
-        acc.d += rec[u].cx;
+        acc.gw += h2[k];
+        acc.d += h2[k + 1];
       }
+      if (!(fl & 2)) break;  // the column ends in that task
+    }
+    if (tk.part >= 0) {
+      // a piece of a column longer than the workgroup's tasks: its sums for fm_finalize_kernel
+      double* row = a.parts + int64_t(tk.part) * (k + 3);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int f = (c * LPR + l) * VEC;
+        if (f < k) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) row[f + v] = acc.m[c][v];
+        }
+      }
+      if (l == 0) {
+        row[k] = acc.gw;
+        row[k + 1] = acc.d;
+        row[k + 2] = any ? a.stamp : 0.0;
+      }
+    } else if (any) {
+      apply_column<LPR, VEC, NC>(acc, vold, tk.last_col, a.V, a.w, a.grad, a.n, k, a.lr, l,
+                                 a.touch, a.touch_id);
     }
   }
-  if (cur >= 0) emit_column<LPR, VEC, NC>(acc, vold, cur, wi, wid, a, l);
 }
 
 // ---------------------------------------------------------------------------
-// 3. columns that cross window borders (carries in window order), hot columns
-//    (slabs in block order) and w0
+// 3. columns split over several tasks: their partial rows, in slot order
 // ---------------------------------------------------------------------------
 struct FinArgs {
-  const CrossCol* cross;  // [n_cross_short | n_cross_long]
-  int32_t n_cross_short;  // few carry rows: one lane group per column
-  int32_t n_cross_long;   // many carry rows: one workgroup per column
-  const int32_t* carry_idx;
-  const double* carries;
+  const SplitCol* split;  // [n_split_short | n_split_long]
+  int32_t n_split_short;  // few partial rows: one lane group per column
+  int32_t n_split_long;   // many partial rows: one workgroup per column
+  const double* parts;
   double stamp;
-  const int32_t* hot_cols;    // hot columns: kHotParts partial rows each, from fm_consume_kernel
-  int32_t n_hot;
-  const double* hot_part;
-  int32_t n_slabs;            // forward workgroups of this step
-  const double* err_partial;  // [n_slabs] per-workgroup sums of the residual
   int32_t k;
   int64_t n;
-  double* w0;
   double* w;
   double* V;
   double lr;
@@ -840,48 +984,21 @@ struct FinArgs {
   int32_t touch_id;
 };
 
-// blocks [0, nb_cross): hot columns (partial rows from fm_consume_kernel) and short
-// crossing columns, one per lane group; then one block per long crossing column;
-// last block: w0 from the forward workgroups' residual sums.
+// blocks [0, nb_short): short split columns, one per lane group; then one block per long
+// split column.  Launched only when the plan has split columns.
 template <int LPR, int VEC, int NC>
-__global__ __launch_bounds__(kBlock) void fm_finalize_kernel(FinArgs a, int nb_cross) {
+__global__ __launch_bounds__(kBlock) void fm_finalize_kernel(FinArgs a, int nb_short) {
   __shared__ double scratch[kBlock];
   __shared__ double tot[1024 + 2];
+  __shared__ int touched;
   const int k = a.k;
   const int b = blockIdx.x;
-  if (b < nb_cross) {
+  if (b < nb_short) {
     constexpr int GPB = kBlock / LPR;
     const int l = threadIdx.x % LPR;
     const int ci = b * GPB + threadIdx.x / LPR;
-    if (ci >= a.n_hot + a.n_cross_short) return;
-    if (ci < a.n_hot) {
-      // a hot column: its kHotParts partial rows, in part order
-      const int32_t col = a.hot_cols[ci];
-      const double* row = a.hot_part + int64_t(ci) * kHotParts * (k + 2);
-      ColAcc<VEC, NC> acc;
-      acc.clear();
-      Pack<VEC> vold[NC];
-#pragma unroll
-      for (int ch = 0; ch < NC; ++ch) {
-        const int f = (ch * LPR + l) * VEC;
-        vold[ch].load(a.V + int64_t(col) * k + (f < k ? f : 0));
-      }
-#pragma unroll
-      for (int p = 0; p < kHotParts; ++p) {
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch) {
-          const int f = (ch * LPR + l) * VEC;
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) acc.m[ch][v] += row[p * (k + 2) + (f < k ? f : 0) + v];
-        }
-        acc.gw += row[p * (k + 2) + k];
-        acc.d += row[p * (k + 2) + k + 1];
-      }
-      apply_column<LPR, VEC, NC>(acc, vold, col, a.V, a.w, a.grad, a.n, k, a.lr, l, a.touch,
-                                 a.touch_id);
-      return;
-    }
-    const CrossCol cc = a.cross[ci - a.n_hot];
+    if (ci >= a.n_split_short) return;
+    const SplitCol cc = a.split[ci];
 
     ColAcc<VEC, NC> acc;
     acc.clear();
@@ -892,14 +1009,14 @@ __global__ __launch_bounds__(kBlock) void fm_finalize_kernel(FinArgs a, int nb_c
       vold[ch].load(a.V + int64_t(cc.col) * k + (f < k ? f : 0));
     }
     bool any = false;
-    constexpr int CB = 4;  // carry rows per trip, loaded unconditionally; stale rows are masked
-    for (int i = 0; i < cc.idx_count; i += CB) {
+    constexpr int CB = 4;  // partial rows per trip, loaded unconditionally; stale rows are masked
+    for (int i = 0; i < cc.part_count; i += CB) {
       const double* row[CB];
       bool in[CB];
 #pragma unroll
       for (int u = 0; u < CB; ++u) {
-        in[u] = i + u < cc.idx_count;
-        row[u] = a.carries + int64_t(a.carry_idx[cc.idx_begin + (in[u] ? i + u : i)]) * (k + 3);
+        in[u] = i + u < cc.part_count;
+        row[u] = a.parts + int64_t(cc.part_begin + (in[u] ? i + u : i)) * (k + 3);
       }
       double mm[CB][NC][VEC], gg[CB], dd[CB], ss[CB];
 #pragma unroll
@@ -931,39 +1048,16 @@ __global__ __launch_bounds__(kBlock) void fm_finalize_kernel(FinArgs a, int nb_c
                                  a.touch_id);
     return;
   }
-  const int lb = b - nb_cross;
-  if (lb < a.n_cross_long) {
-    const CrossCol cc = a.cross[a.n_cross_short + lb];
-    const int32_t col = cc.col;
-    ordered_carry_sum(a.carries, a.carry_idx + cc.idx_begin, cc.idx_count, k, a.stamp, scratch,
-                      tot);
-    const double gw = tot[k], d = tot[k + 1];
-    for (int f = threadIdx.x; f < k; f += kBlock) {
-      const int64_t at = int64_t(col) * k + f;
-      if (a.grad)
-        a.grad[at] = d * a.V[at] - tot[f];
-      else
-        a.V[at] += a.lr * (tot[f] - d * a.V[at]);
-    }
-    if (threadIdx.x == 0) {
-      if (a.grad) {
-        a.grad[a.n * k + col] = -gw;
-        if (a.touch) a.touch[col] = a.touch_id;
-      } else {
-        a.w[col] += a.lr * gw;
-      }
-    }
-    return;
-  }
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < a.n_slabs; i += kBlock) acc += a.err_partial[i];
-  const double s = block_sum<kBlock>(acc, scratch);
-  if (threadIdx.x == 0) {
-    if (a.grad)
-      a.grad[a.n * k + a.n] = -s;
-    else
-      a.w0[0] += a.lr * s;
-  }
+  const SplitCol cc = a.split[a.n_split_short + (b - nb_short)];
+  // is any partial row of this step's?  (an untouched column is left alone)
+  if (threadIdx.x == 0) touched = 0;
+  __syncthreads();
+  for (int r = threadIdx.x; r < cc.part_count; r += kBlock)
+    if (a.parts[int64_t(cc.part_begin + r) * (k + 3) + k + 2] == a.stamp) touched = 1;
+  __syncthreads();
+  if (!touched) return;
+  ordered_part_sum(a.parts, cc.part_begin, cc.part_count, k, a.stamp, scratch, tot);
+  apply_column_block(tot, cc.col, a.V, a.w, a.grad, a.n, k, a.lr, a.touch, a.touch_id);
 }
 
 // RFM_CHECK_IDS=1: the row ids of one step must lie in the log and be distinct (a row's

@@ -10,11 +10,13 @@ struct rfm_fm_plan {
   int32_t device = 0;
   int64_t n_rows = 0, n_features = 0, nnz = 0, n_slots = 0, max_batch = 0;
   int32_t k = 0;
-  int32_t n_win = 0, n_cross_short = 0, n_cross_long = 0, n_hot = 0;
-  int64_t step = 0;  // stamps the carries of a step
+  int32_t n_task_blocks = 0;  // workgroups of fm_consume_kernel that process tasks
+  int32_t task_words = 1;     // 64-slot words per task
+  int32_t n_split_short = 0, n_split_long = 0, n_parts = 0, n_hot = 0;
+  int64_t step = 0;  // stamps the partial rows of a step
   int32_t fwd_grid_max = 0;  // forward workgroups of a max_batch step (= hot-sum slabs)
-  rfm::DevBuf ent, rows, slot_t, slots, win, cross, carry_idx, carries, Q, err, hot_cols,
-      hot_slab, hot_part, err_partial;
+  rfm::DevBuf ent, rows, slot_t, slot_bits, slots, tasks, split, parts, Q, err, hot_cols, hot_slab,
+      err_partial;
   rfm::DevBuf loss_rows;  // rfm_fm_train: per-workgroup loss partials of a run of iterations
   std::vector<int32_t> h_hot_cols;  // host copy of hot_cols (rfm_fm_plan_hot_columns)
   // touched-row gradients (rfm_fm_grad_rows), allocated on first use: the gradient table
@@ -25,9 +27,9 @@ struct rfm_fm_plan {
   rfm::DevBuf ids_seen, ids_flags;  // RFM_CHECK_IDS=1: validation of the steps' row ids
   int32_t ids_stamp = 0;
   size_t device_bytes() const {
-    return ent.bytes + rows.bytes + slot_t.bytes + slots.bytes + win.bytes + cross.bytes +
-           carry_idx.bytes + carries.bytes + Q.bytes + err.bytes + hot_cols.bytes +
-           hot_slab.bytes + hot_part.bytes + err_partial.bytes;
+    return ent.bytes + rows.bytes + slot_t.bytes + slot_bits.bytes + slots.bytes + tasks.bytes +
+           split.bytes + parts.bytes + Q.bytes + err.bytes + hot_cols.bytes + hot_slab.bytes +
+           err_partial.bytes;
   }
 };
 
@@ -39,11 +41,11 @@ namespace rfm {
 constexpr size_t kHotLdsBudget = 56 << 10;
 constexpr int kMaxHot = 160;  // beyond this the slab traffic outweighs what the class saves
 constexpr int32_t kDefaultHotMinCount = 32;
-constexpr int32_t kShortCross = 8;  // crossing columns up to this many carry rows: one lane group
+constexpr int32_t kShortSplit = 8;   // split columns up to this many partial rows: one lane group
+// fm_consume_kernel's tasks: task_words is the power of two for which a task expects about
+// kTaskMarks marked slots per max_batch step (at most kTaskTrips words per lane of a group)
+constexpr int kTaskMarks = 6;
 constexpr int kMaxFwdGrid = 2048;   // upper bound of the forward's grid, sizes scratch
-
-// slots per window of fm_consume_kernel for a lane-group width (WinShape<LPR>::WIN)
-inline int window_slots(int lpr) { return lpr >= 64 ? 64 : (lpr == 32 ? 64 : 4 * lpr); }
 
 inline int env_int(const char* name, int dflt) {
   const char* v = getenv(name);

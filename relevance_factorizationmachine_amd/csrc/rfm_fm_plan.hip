@@ -109,7 +109,6 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
   RFM_REQUIRE(ctx && d_indptr && d_y && d_pscore, "null pointer");
   RFM_REQUIRE(n_rows >= 1 && n_features >= 1 && max_batch >= 1, "bad shape");
   RFM_REQUIRE(n_rows < (int64_t(1) << 31), "too many rows");
-  const Shape shp = shape_for(n_factors);
   RFM_REQUIRE(n_features < (int64_t(1) << 31) - 2, "n_features too large");
   RFM_HIP_CHECK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -205,57 +204,90 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
     std::sort(hot_cols.begin(), hot_cols.end());
     for (size_t h = 0; h < hot_cols.size(); ++h) hot_rank[size_t(hot_cols[h])] = int32_t(h);
   }
-  std::vector<int64_t> cptr(nf + 1, 0);  // slots of the sparse class, column-major
+  // tasks of fm_consume_kernel: the slot view is cut into tasks of task_words x 64 slots, one
+  // per lane group, GPB of them per workgroup.  The sparse-class columns are laid out in
+  // ascending order; a column may run over several tasks, but it never crosses the edge of a
+  // workgroup's slots unless it is longer than all of them (then it starts on such an edge,
+  // takes whole workgroups -- each leaves one partial row for fm_finalize_kernel -- and the
+  // rest of its last workgroup stays empty).
+  const Shape shp = shape_for(n_factors);
+  const int64_t GPB = kBlock / shp.lpr;
+  const double density = double(max_batch) / double(n_rows);  // marked fraction of a column
+  int64_t W = 1;
+  while (W * 2 * 64 * density <= kTaskMarks && W * 2 <= int64_t(kTaskTrips) * shp.lpr) W *= 2;
+  W = std::max<int64_t>(1, std::min<int64_t>(W, env_int("RFM_TASK_WORDS", int(W))));
+  const int64_t C = W * 64;     // slots of a task
+  const int64_t BC = GPB * C;   // slots of a workgroup
+  std::vector<int64_t> cptr(nf, 0);  // first slot of every sparse-class column
   std::vector<int32_t> colinfo(nf);
+  std::vector<SplitCol> split_short, split_long;
+  std::vector<std::pair<int64_t, int32_t>> piece_blocks;  // (workgroup, partial row)
+  int64_t at = 0;
+  int32_t n_parts = 0;
   for (size_t c = 0; c < nf; ++c) {
-    cptr[c + 1] = cptr[c] + (hot_rank[c] >= 0 ? 0 : len(c));
-    colinfo[c] = hot_rank[c] >= 0 ? kHotTag + hot_rank[c] : int32_t(cptr[c] - int64_t(h_start[c]));
+    if (hot_rank[c] >= 0) {
+      colinfo[c] = kHotTag + hot_rank[c];
+      continue;
+    }
+    const int64_t lc = len(c);
+    if (lc == 0) {
+      cptr[c] = at;
+      colinfo[c] = 0;
+      continue;
+    }
+    if (lc <= BC) {
+      const int64_t room = BC - at % BC;
+      if (lc > room) at += room;
+      cptr[c] = at;
+      at += lc;
+    } else {
+      at = (at + BC - 1) / BC * BC;
+      cptr[c] = at;
+      const int64_t n_blk = (lc + BC - 1) / BC;
+      SplitCol sc{int32_t(c), n_parts, int32_t(n_blk), 0};
+      for (int64_t b = 0; b < n_blk; ++b) piece_blocks.emplace_back(at / BC + b, n_parts++);
+      at += n_blk * BC;
+      (sc.part_count <= kShortSplit ? split_short : split_long).push_back(sc);
+    }
+    colinfo[c] = int32_t(cptr[c] - int64_t(h_start[c]));
   }
-  const int64_t n_slots = cptr[nf];
+  const int64_t n_blocks = std::max<int64_t>(1, (at + BC - 1) / BC);
+  const int64_t n_slots = n_blocks * BC;
+  RFM_REQUIRE(n_slots < (int64_t(1) << 31) - 512, "slot space too large");
   const size_t ns = size_t(n_slots);
-  // fixed slot windows (one per lane group of fm_consume_kernel) and the columns that cross a
-  // window border, with the carry rows they collect in window order
-  const int64_t WIN = window_slots(shp.lpr);
-  const int64_t n_win = (n_slots + WIN - 1) / WIN;
-  RFM_REQUIRE(n_win * 2 < (int64_t(1) << 31), "too many slot windows");
-  std::vector<WinInfo> win(size_t(n_win) + 1, WinInfo{0, 0, 0, 0});
+  // task descriptions: the columns of the first and last occupied slot of every task, and
+  // whether they continue from / into the neighbouring task of the same workgroup
+  std::vector<TaskRec> tasks(size_t(n_blocks * GPB), TaskRec{-1, -1, 0, -1});
   {
-    size_t cf = 0, cl = 0;  // column cursors of the windows' first and last slots
-    for (int64_t w = 0; w < n_win; ++w) {
-      const int64_t b0 = w * WIN, e0 = std::min(n_slots, b0 + WIN);
-      while (cptr[cf + 1] <= b0) ++cf;
-      if (cl < cf) cl = cf;
-      while (cptr[cl + 1] <= e0 - 1) ++cl;
-      int32_t flags_w = 0;
-      if (cptr[cf] < b0 || cptr[cf + 1] > e0) flags_w |= 1;
-      if (cl != cf && cptr[cl + 1] > e0) flags_w |= 2;
-      win[size_t(w)] = WinInfo{int32_t(cf), int32_t(cl), flags_w, 0};
+    size_t c = 0;  // cursor: first sparse column whose slots end after the task's start
+    const auto cend = [&](size_t cc) { return cptr[cc] + (hot_rank[cc] >= 0 ? 0 : len(cc)); };
+    for (int64_t t = 0; t < n_blocks * GPB; ++t) {
+      const int64_t b0 = t * C, e0 = b0 + C;
+      while (c < nf && (hot_rank[c] >= 0 || len(c) == 0 || cend(c) <= b0)) ++c;
+      if (c >= nf || cptr[c] >= e0) continue;  // nothing in this task
+      size_t cl = c;  // last column with a slot in the task
+      for (size_t nx = c + 1; nx < nf && cptr[nx] < e0; ++nx)
+        if (hot_rank[nx] < 0 && len(nx) > 0) cl = nx;
+      TaskRec& tr = tasks[size_t(t)];
+      tr.first_col = int32_t(c);
+      tr.last_col = int32_t(cl);
+      const bool first_in_block = t % GPB == 0, last_in_block = t % GPB == GPB - 1;
+      if (cptr[c] < b0 && !first_in_block) tr.flags |= 1;
+      if (cend(cl) > e0 && !last_in_block) tr.flags |= 2;
     }
   }
-  std::vector<CrossCol> cross_short, cross_long;
-  std::vector<int32_t> carry_idx;
-  for (size_t c = 0; c < nf; ++c) {
-    const int64_t b0 = cptr[c], e0 = cptr[c + 1];
-    if (e0 <= b0) continue;
-    const int64_t wf = b0 / WIN, wl = (e0 - 1) / WIN;
-    if (wf == wl) continue;
-    CrossCol cc{int32_t(c), int32_t(carry_idx.size()), 0, 0};
-    for (int64_t w = wf; w <= wl; ++w) {
-      const int which = win[size_t(w)].first_col == int32_t(c) ? 0 : 1;
-      carry_idx.push_back(int32_t(w * 2 + which));
-      cc.idx_count++;
-    }
-    (cc.idx_count <= kShortCross ? cross_short : cross_long).push_back(cc);
-  }
-  std::vector<CrossCol> cross(cross_short);
-  cross.insert(cross.end(), cross_long.begin(), cross_long.end());
-  lap("classes, windows, crossing lists (host)");
+  for (const auto& pb : piece_blocks) tasks[size_t(pb.first * GPB)].part = pb.second;
+  std::vector<SplitCol> split(split_short);
+  split.insert(split.end(), split_long.begin(), split_long.end());
+  lap("classes, tasks, split columns (host)");
 
   // ---- entry and slot records ----------------------------------------------------------
   plan->n_slots = n_slots;
-  plan->n_win = int32_t(n_win);
-  plan->n_cross_short = int32_t(cross_short.size());
-  plan->n_cross_long = int32_t(cross_long.size());
+  plan->n_task_blocks = int32_t(n_blocks);
+  plan->task_words = int32_t(W);
+  plan->n_split_short = int32_t(split_short.size());
+  plan->n_split_long = int32_t(split_long.size());
+  plan->n_parts = n_parts;
   plan->n_hot = int32_t(hot_cols.size());
   plan->h_hot_cols = hot_cols;
   plan->fwd_grid_max = forward_grid(ctx, max_batch, n_factors);
@@ -263,26 +295,27 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
   upload(d_colinfo, colinfo.data(), nf * 4, st);
   plan->ent.alloc((nz + 1) * sizeof(Entry));  // +1: clamp target of empty logs
   RFM_HIP_CHECK(hipMemsetAsync(plan->ent.as<Entry>() + nz, 0, sizeof(Entry), st));
-  plan->slots.alloc((ns + 256) * sizeof(SlotRec));  // padded by one window
-  RFM_HIP_CHECK(hipMemsetAsync(plan->slots.as<SlotRec>() + ns, 0, 256 * sizeof(SlotRec), st));
+  // (slots between tasks -- the padding to whole bitmap words -- are never marked)
+  plan->slots.alloc((ns + 256) * sizeof(SlotRec));
+  RFM_HIP_CHECK(hipMemsetAsync(plan->slots.p, 0, plan->slots.bytes, st));
   if (nnz > 0) {
     hipLaunchKernelGGL(plan_scatter_kernel, dim3(grid_for(ctx, nnz)), dim3(kBlock), 0, st,
                        key.as<int32_t>(), pos.as<int32_t>(), d_values, d_colinfo.as<int32_t>(),
                        nnz, plan->ent.as<Entry>(), plan->slots.as<SlotRec>());
     RFM_HIP_CHECK(hipGetLastError());
   }
-  upload(plan->win, win.data(), win.size() * sizeof(WinInfo), st);
-  upload(plan->cross, cross.data(), cross.size() * sizeof(CrossCol), st);
-  upload(plan->carry_idx, carry_idx.data(), carry_idx.size() * 4, st);
+  upload(plan->tasks, tasks.data(), tasks.size() * sizeof(TaskRec), st);
+  upload(plan->split, split.data(), split.size() * sizeof(SplitCol), st);
   upload(plan->hot_cols, hot_cols.data(), hot_cols.size() * 4, st);
-  plan->slot_t.alloc((ns + 256) * 4);
-  RFM_HIP_CHECK(hipMemsetAsync(plan->slot_t.p, 0xFF, plan->slot_t.bytes, st));
-  // carry rows [n_win*2][k+3]; stamp 0 never matches a step id (they start at 1)
-  plan->carries.alloc(std::max<size_t>(size_t(n_win) * 2, 1) * size_t(n_factors + 3) * 8);
-  RFM_HIP_CHECK(hipMemsetAsync(plan->carries.p, 0, plan->carries.bytes, st));
+  plan->slot_t.alloc((ns + 256) * sizeof(SlotMark));
+  RFM_HIP_CHECK(hipMemsetAsync(plan->slot_t.p, 0, plan->slot_t.bytes, st));
+  plan->slot_bits.alloc((ns / 64 + 8) * 8);
+  RFM_HIP_CHECK(hipMemsetAsync(plan->slot_bits.p, 0, plan->slot_bits.bytes, st));
+  // partial rows [n_parts][k+3]; stamp 0 never matches a step id (they start at 1)
+  plan->parts.alloc(std::max<size_t>(size_t(n_parts), 1) * size_t(n_factors + 3) * 8);
+  RFM_HIP_CHECK(hipMemsetAsync(plan->parts.p, 0, plan->parts.bytes, st));
   plan->hot_slab.alloc(size_t(kMaxFwdGrid) * std::max<size_t>(hot_cols.size(), 1) *
                        size_t(n_factors + 2) * 8);
-  plan->hot_part.alloc(std::max<size_t>(hot_cols.size(), 1) * kHotParts * size_t(n_factors + 2) * 8);
   plan->err_partial.alloc(size_t(kMaxFwdGrid) * 8);
   plan->Q.alloc(size_t(max_batch) * size_t(n_factors) * 8);
   plan->err.alloc(size_t(max_batch) * 8);
@@ -350,14 +383,14 @@ int32_t rfm_fm_plan_destroy(rfm_fm_plan* plan) {
 int32_t rfm_fm_plan_info(const rfm_fm_plan* plan, int64_t* h_out8) {
   return guarded([&] {
     RFM_REQUIRE(plan && h_out8, "null pointer");
-    h_out8[0] = plan->n_win;
-    h_out8[1] = plan->n_cross_short + plan->n_cross_long;
+    h_out8[0] = int64_t(plan->n_task_blocks) * (rfm::kBlock / rfm::shape_for(plan->k).lpr);
+    h_out8[1] = plan->n_split_short + plan->n_split_long;
     h_out8[2] = plan->n_hot;
     h_out8[3] = plan->nnz;
     h_out8[4] = int64_t(plan->device_bytes());
     h_out8[5] = plan->fwd_grid_max;
     h_out8[6] = plan->n_slots;
-    h_out8[7] = 0;
+    h_out8[7] = plan->task_words;
   });
 }
 

@@ -24,17 +24,24 @@ struct SlotRec {  // one slot of the column-major view, 16 B
   int32_t col;    // feature column
   int32_t pad;
 };
-struct WinInfo {      // static description of one slot window, 16 B
-  int32_t first_col;  // column of the window's first slot
-  int32_t last_col;   // column of its last slot
-  int32_t flags;      // bit0: first column is not wholly inside the window
-                      // bit1: last column (!= first) continues after the window
+struct SlotMark {  // what the forward leaves at a marked slot, 16 B
+  int32_t t;       // batch position of the slot's row
   int32_t pad;
+  double err;      // the row's residual y/p - sigmoid(logit)
 };
-struct CrossCol {      // a sparse-class column spanning more than one window
+struct TaskRec {      // one task of fm_consume_kernel: task_words x 64 consecutive slots; 16 B
+  int32_t first_col;  // column of the task's first occupied slot
+  int32_t last_col;   // column of its last occupied slot
+  int32_t flags;      // bit0: first_col continues from the previous task (same workgroup)
+                      // bit1: last_col continues into the next task (same workgroup)
+  int32_t part;       // >= 0: the task starts a workgroup that lies inside a column longer than a
+                      // workgroup's tasks; the workgroup's sums go to this partial row
+};
+constexpr int kTaskTrips = 4;  // a lane loads up to this many bitmap words of its task
+struct SplitCol {      // a sparse-class column longer than a whole workgroup's tasks
   int32_t col;
-  int32_t idx_begin;   // its carry rows: carry_idx[idx_begin .. +idx_count)
-  int32_t idx_count;
+  int32_t part_begin;  // its partial rows: parts[part_begin .. +part_count), in slot order
+  int32_t part_count;
   int32_t pad;
 };
 

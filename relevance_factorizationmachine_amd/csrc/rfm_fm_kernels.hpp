@@ -845,7 +845,14 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
         for (int ch = 0; ch < NC; ++ch) {
           const int f = (ch * LPR + l) * VEC;
           qq[u][ch].load(a.Q + int64_t(rec[u].t) * k + (f < k ? f : 0));
-          vv[u][ch].load(a.V + int64_t(rec[u].col) * k + (f < k ? f : 0));
+        }
+        // (an entry of the column the one before it belongs to needs no V row)
+        if (rec[u].col != (u == 0 ? cur : rec[u > 0 ? u - 1 : 0].col)) {
+#pragma unroll
+          for (int ch = 0; ch < NC; ++ch) {
+            const int f = (ch * LPR + l) * VEC;
+            vv[u][ch].load(a.V + int64_t(rec[u].col) * k + (f < k ? f : 0));
+          }
         }
       }
 #pragma unroll

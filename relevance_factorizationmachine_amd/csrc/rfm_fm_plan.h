@@ -44,7 +44,7 @@ constexpr int32_t kDefaultHotMinCount = 32;
 constexpr int32_t kShortSplit = 8;   // split columns up to this many partial rows: one lane group
 // fm_consume_kernel's tasks: task_words is the power of two for which a task expects about
 // kTaskMarks marked slots per max_batch step (at most kTaskTrips words per lane of a group)
-constexpr int kTaskMarks = 6;
+constexpr int kTaskMarks = 8;
 constexpr int kMaxFwdGrid = 2048;   // upper bound of the forward's grid, sizes scratch
 
 inline int env_int(const char* name, int dflt) {

@@ -214,8 +214,9 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
   const int64_t GPB = kBlock / shp.lpr;
   const double density = double(max_batch) / double(n_rows);  // marked fraction of a column
   int64_t W = 1;
-  while (W * 2 * 64 * density <= kTaskMarks && W * 2 <= int64_t(kTaskTrips) * shp.lpr) W *= 2;
-  W = std::max<int64_t>(1, std::min<int64_t>(W, env_int("RFM_TASK_WORDS", int(W))));
+  while (W * 2 * 64 * density <= 1.5 * kTaskMarks && W * 2 <= int64_t(kTaskTrips) * shp.lpr) W *= 2;
+  if (const int forced = env_int("RFM_TASK_WORDS", 0))  // tuning experiments only
+    W = std::max<int64_t>(1, std::min<int64_t>(forced, int64_t(kTaskTrips) * shp.lpr));
   const int64_t C = W * 64;     // slots of a task
   const int64_t BC = GPB * C;   // slots of a workgroup
   std::vector<int64_t> cptr(nf, 0);  // first slot of every sparse-class column

@@ -37,7 +37,7 @@ struct TaskRec {      // one task of fm_consume_kernel: task_words x 64 consecut
   int32_t part;       // >= 0: the task starts a workgroup that lies inside a column longer than a
                       // workgroup's tasks; the workgroup's sums go to this partial row
 };
-constexpr int kTaskTrips = 4;  // a lane loads up to this many bitmap words of its task
+constexpr int kTaskTrips = 1;  // bitmap words of its task a lane loads (task_words <= lanes of a group)
 struct SplitCol {      // a sparse-class column longer than a whole workgroup's tasks
   int32_t col;
   int32_t part_begin;  // its partial rows: parts[part_begin .. +part_count), in slot order

@@ -1,7 +1,8 @@
 #!/bin/bash
-# Runs on the GPU box (through gpurun): parity tests, the bench line, and the
-# rocprofv3 kernel-trace summary of the same bench command.  Outputs land in
-# gpurun_out/<tag>/ ; the summaries worth keeping are copied to profiles/ by hand.
+# Runs on the GPU box (through gpurun): parity tests, the bench line (which collects its own
+# PMC traffic passes: gpurun_out/bench_pmc/pmc_summary.json), and the rocprofv3 kernel-trace
+# summary of the same bench command.  Outputs land in gpurun_out/<tag>/ ; what is worth
+# keeping is copied to profiles/<tag>/ by hand (with the commit it was taken at).
 #   usage: profiles/collect.sh <tag> [bench args...]
 set -o pipefail
 TAG=${1:-run}; shift
@@ -9,26 +10,20 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$R"
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
+timeout -k 10 900 python -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1
 echo "pytest exit=$?" | tee -a "$OUT/pytest_gpu.log"
-tail -5 "$OUT/pytest_gpu.log"
-timeout -k 10 600 python bench.py "$@" > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; tail -20 "$OUT/bench.err"; }
-cat "$OUT/bench.json"
+tail -3 "$OUT/pytest_gpu.log"
+timeout -k 10 900 python bench.py "$@" > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; tail -20 "$OUT/bench.err"; }
+cp gpurun_out/bench_pmc/pmc_summary.json "$OUT/pmc_summary.json" 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- \
-  python3 "$R/bench.py" "$@" --no-cpu-baseline --no-extra > "$OUT/prof_bench.json" 2> "$OUT/prof.err" || { echo "rocprof failed"; tail -20 "$OUT/prof.err"; }
-find "$OUT/prof" -name "*kernel_stats*.csv" | head -3
+  python3 "$R/bench.py" "$@" --no-cpu-baseline --no-extra --no-pmc > "$OUT/bench_under_rocprof.json" 2> "$OUT/prof.err" || { echo "rocprof failed"; tail -20 "$OUT/prof.err"; }
 F=$(find "$OUT/prof" -name "*kernel_stats*.csv" | head -1)
-[ -n "$F" ] && cp "$F" "$OUT/kernel_stats.csv" && head -12 "$OUT/kernel_stats.csv"
-# the per-dispatch trace is large: keep only the stats
-find "$OUT/prof" -name "*kernel_trace*.csv" -size +2M -delete
-# HBM traffic: FETCH_SIZE and WRITE_SIZE in their own passes (TCC slots do not fit both)
-cd /tmp
-for C in fetch:FETCH_SIZE write:WRITE_SIZE; do
-  timeout -k 10 600 rocprofv3 --pmc ${C#*:} --kernel-trace --output-format csv -d "$OUT/pmc_${C%%:*}" -- \
-    python3 "$R/bench.py" "$@" --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc_${C%%:*}.err" || { echo "pmc ${C#*:} failed"; tail -5 "$OUT/pmc_${C%%:*}.err"; }
-done
-cd "$R"
-python profiles/pmc_summary.py "$OUT" 65536 "$OUT/traffic.json" > "$OUT/pmc_summary.json" 2>&1; cat "$OUT/pmc_summary.json" | head -40
-find "$OUT" -name "*kernel_trace*.csv" -size +2M -delete
-find "$OUT" -name "*counter_collection*.csv" -size +8M -delete
+[ -n "$F" ] && cp "$F" "$OUT/kernel_stats.csv" && head -8 "$OUT/kernel_stats.csv" | cut -c1-150
+rm -rf "$OUT/prof"
+# the reference's own batch size under the kernel trace as well
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof2k" -- \
+  python3 "$R/bench.py" --batch-size 2000 --steps 200 --warmup 20 "$@" --no-cpu-baseline --no-extra --no-pmc > "$OUT/bench_b2000_under_rocprof.json" 2>> "$OUT/prof.err"
+F=$(find "$OUT/prof2k" -name "*kernel_stats*.csv" | head -1)
+[ -n "$F" ] && cp "$F" "$OUT/kernel_stats_b2000.csv" && head -6 "$OUT/kernel_stats_b2000.csv" | cut -c1-150
+rm -rf "$OUT/prof2k"

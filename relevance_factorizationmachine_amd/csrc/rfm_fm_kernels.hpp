@@ -100,6 +100,11 @@ constexpr int kBigBlock = RFM_FWD_BIG_BLOCK;  // threads of the forward's many-r
 #define RFM_FWD_ROWS 2
 #endif
 
+// entries of a row whose V gathers the one-row forward shape keeps in flight
+#ifndef RFM_FWD_SMALL_UNROLL
+#define RFM_FWD_SMALL_UNROLL 8
+#endif
+
 // rows a lane group works on concurrently (independent load chains in flight)
 constexpr int rows_in_flight(int nc) { return nc == 1 ? RFM_FWD_ROWS : 1; }
 
@@ -280,7 +285,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
         ebuf[i * LPR + l] = e[i];
       }
       const int cnt = (maxlen - pb) < LPR ? (maxlen - pb) : LPR;
-#pragma unroll 2
+      // entries whose gathers are in flight together: the many-rows shape is at its register
+      // budget with two (x R rows); the one-row shape has registers to spare
+#pragma unroll(BLOCK == kBigBlock || NC > 1 ? 2 : RFM_FWD_SMALL_UNROLL)
       for (int j = 0; j < cnt; ++j) {
         Entry ej[R];
         Pack<VEC> pv[R][NC];

@@ -21,6 +21,80 @@ from .optimizer import DeviceSGD
 from .runtime import BatchIdStream, Runtime, mf_schedule_ex
 
 
+class _SchedulePipe:
+    """Host side of the exact MF batches, off the critical path: a producer thread derives the
+    level schedule of the coming iterations (``rfm_mf_schedule_ex``; ctypes releases the GIL)
+    and packs it -- records, level pointers, cached items -- into a ring of PINNED host
+    buffers; the consumer enqueues one asynchronous copy per iteration into the matching
+    device slot and launches.  A host slot is handed back to the producer only after the copy
+    out of it has completed (an event), a device slot is reused ``DEPTH`` iterations later on
+    the same stream, i.e. after the kernels that read it."""
+
+    DEPTH = 8
+
+    def __init__(self, rt: Runtime, batch_size: int, cache_cap: int):
+        import queue
+
+        import torch
+
+        self.rt, self.B, self.cache_cap = rt, batch_size, cache_cap
+        self.ex_bytes = 24 * batch_size
+        self.lptr_off = (self.ex_bytes + 15) // 16 * 16
+        self.cache_off = (self.lptr_off + 4 * (batch_size + 1) + 15) // 16 * 16
+        self.total = self.cache_off + 4 * max(cache_cap, 1)
+        self.host = [torch.empty(self.total, dtype=torch.uint8, pin_memory=True) for _ in range(self.DEPTH)]
+        self.dev = [rt.empty((self.total,), torch.uint8) for _ in range(self.DEPTH)]
+        self.free: "queue.Queue" = queue.Queue()
+        for s in range(self.DEPTH):
+            self.free.put((s, None))
+        self.ready: "queue.Queue" = queue.Queue(maxsize=self.DEPTH)
+        self.torch = torch
+
+    def produce(self, epochs, schedule_fn) -> None:
+        """Runs in the producer thread: ``schedule_fn(rows) -> (ex, level_ptr, cache_items)``
+        for every ``(epoch, rows, ids_ptr)`` of ``epochs``."""
+        try:
+            for epoch, rows, ids_ptr in epochs:
+                slot, ev = self.free.get()
+                if slot is None:
+                    return
+                if ev is not None:
+                    ev.synchronize()  # the copy out of this host slot has completed
+                ex, level_ptr, cache_items = schedule_fn(rows)
+                h = self.host[slot].numpy()
+                h[: self.ex_bytes] = ex.view(np.uint8)
+                h[self.lptr_off: self.lptr_off + 4 * len(level_ptr)] = level_ptr.view(np.uint8)
+                h[self.cache_off: self.cache_off + 4 * len(cache_items)] = cache_items.view(np.uint8)
+                self.ready.put((epoch, ids_ptr, slot, len(level_ptr) - 1, len(cache_items)))
+            self.ready.put(None)
+        except BaseException as exc:  # noqa: BLE001 -- handed to the consumer
+            self.ready.put(exc)
+
+    def take(self):
+        """Next iteration: enqueues the copy and returns ``(epoch, ids_ptr, device ex ptr, HOST
+        level_ptr ptr, device level_ptr ptr, n_levels, device cache ptr, n_cached, done)``;
+        call ``done()`` after the launches that read the slot have been enqueued."""
+        item = self.ready.get()
+        if item is None:
+            return None
+        if isinstance(item, BaseException):
+            raise item
+        epoch, ids_ptr, slot, n_levels, n_cached = item
+        self.dev[slot].copy_(self.host[slot], non_blocking=True)
+        ev = self.torch.cuda.Event()
+        ev.record()
+        base, hbase = self.dev[slot].data_ptr(), self.host[slot].data_ptr()
+
+        def done() -> None:
+            self.free.put((slot, ev))
+
+        return (epoch, ids_ptr, base, hbase + self.lptr_off, base + self.lptr_off, n_levels,
+                base + self.cache_off, n_cached, done)
+
+    def stop(self) -> None:
+        self.free.put((None, None))
+
+
 class DevicePairs:
     """(user, item) pairs of a log in HBM as two int32 arrays."""
 
@@ -97,6 +171,7 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
         # resample(..., random_state=epoch) ids (src/mf.py:88-95), sampled chunk by chunk on
         # the host while the GPU works on the chunk before
         id_stream = BatchIdStream(rt, n_rows, self.batch_size, self.n_epochs)
+        self._keep_ids = []
 
         tr = DevicePairs(rt, train["features"])
         va = DevicePairs(rt, val["features"])
@@ -113,7 +188,6 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
         params = (self.P.dev.data_ptr(), self.Q.dev.data_ptr(), self.b_u.dev.data_ptr(),
                   self.b_i.dev.data_ptr())
         b = float(self.b)
-        keep = []  # device buffers of in-flight iterations
         h_y = np.ascontiguousarray(train["labels"], dtype=np.float64)
         h_p = np.ascontiguousarray(train["pscores"], dtype=np.float64)
         # item rows the sequential kernel may keep in LDS (32 KiB of rows + bias)
@@ -130,24 +204,7 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
                 self._check_ids(ev_pairs)
                 ev_loop = EvalLoop(rt, ev_frame, self.evaluator, self.estimator, self.n_epochs)
 
-        for epoch, rows, ids_ptr in self._epochs(id_stream):
-            if self.hogwild:
-                _lib.check(rt.lib.rfm_mf_sgd_hogwild(
-                    rt.ctx, tr.users.data_ptr(), tr.items.data_ptr(), y.data_ptr(), p.data_ptr(),
-                    ids_ptr, self.batch_size, *params, b, self.n_factors, float(self.lr),
-                    float(self.reg)))
-            else:
-                ex, level_ptr, cache_items = mf_schedule_ex(
-                    tr.h_users[rows], tr.h_items[rows], h_y[rows], h_p[rows], self.n_users,
-                    self.n_items, cache_cap)
-                d_ex = rt.upload(ex.view(np.uint8))
-                d_lptr = rt.upload(level_ptr)
-                d_cache = rt.upload(cache_items if cache_items.size else np.zeros(1, np.int32))
-                keep.append((d_ex, d_lptr, d_cache))
-                _lib.check(rt.lib.rfm_mf_sgd_levels_ex(
-                    rt.ctx, d_ex.data_ptr(), level_ptr.ctypes.data, d_lptr.data_ptr(),
-                    len(level_ptr) - 1, d_cache.data_ptr(), int(cache_items.size), *params, b,
-                    self.n_factors, float(self.lr), float(self.reg)))
+        def after_sgd(epoch: int, ids_ptr: int) -> None:
             # train loss on the same batch with the updated parameters (src/mf.py:110-116)
             _lib.check(rt.lib.rfm_mf_predict_loss(
                 rt.ctx, tr.users.data_ptr(), tr.items.data_ptr(), y.data_ptr(), p.data_ptr(),
@@ -166,10 +223,45 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
                 y_scores = self.predict(self.evaluator.features[self.model_name])
                 self.val_metrics.append(
                     self.evaluator.evaluate(y_scores=y_scores, estimator=self.estimator))
-            if len(keep) > 64:
+
+        if self.hogwild:
+            for epoch, rows, ids_ptr in self._epochs(id_stream):
+                _lib.check(rt.lib.rfm_mf_sgd_hogwild(
+                    rt.ctx, tr.users.data_ptr(), tr.items.data_ptr(), y.data_ptr(), p.data_ptr(),
+                    ids_ptr, self.batch_size, *params, b, self.n_factors, float(self.lr),
+                    float(self.reg)))
+                after_sgd(epoch, ids_ptr)
+        else:
+            # exact mode: the level schedules of the coming batches are derived and staged by
+            # a host thread while the GPU runs the batch before (the GPU never waits for them)
+            import threading
+
+            pipe = _SchedulePipe(rt, self.batch_size, cache_cap)
+
+            def schedule(rows):
+                return mf_schedule_ex(tr.h_users[rows], tr.h_items[rows], h_y[rows], h_p[rows],
+                                      self.n_users, self.n_items, cache_cap)
+
+            worker = threading.Thread(target=pipe.produce, args=(self._epochs(id_stream), schedule),
+                                      name="rfm-mf-schedule", daemon=True)
+            worker.start()
+            try:
+                while True:
+                    got = pipe.take()
+                    if got is None:
+                        break
+                    epoch, ids_ptr, d_ex, h_lptr, d_lptr, n_levels, d_cache, n_cached, done = got
+                    _lib.check(rt.lib.rfm_mf_sgd_levels_ex(
+                        rt.ctx, d_ex, h_lptr, d_lptr, n_levels, d_cache, n_cached, *params, b,
+                        self.n_factors, float(self.lr), float(self.reg)))
+                    done()
+                    after_sgd(epoch, ids_ptr)
+            finally:
+                pipe.stop()
                 rt.sync()
-                keep.clear()
+                worker.join(timeout=5.0)
         rt.sync()
+        self._keep_ids = []
         if ev_frame is not None:
             self.val_metrics.extend(ev_loop.finish(self.n_epochs))
             self.evaluator_host_calls = ev_loop.host_calls
@@ -180,6 +272,7 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
     def _epochs(self, id_stream: BatchIdStream):
         """``(epoch, host row ids, device address of the ids)`` of every iteration."""
         for first, host_ids, dev_ids in id_stream.chunks():
+            self._keep_ids.append(dev_ids)  # launches enqueued later still read these ids
             for j in range(host_ids.shape[0]):
                 yield first + j, host_ids[j], dev_ids.data_ptr() + j * self.batch_size * 4
 

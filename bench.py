@@ -192,14 +192,14 @@ def compulsory_bytes(X, rows: np.ndarray, k: int, hot_cols: np.ndarray, n_slabs:
     slab = n_slabs * H * (k + 2) * 8
     fwd = (B * 4 + B * 32 + nnz * 16          # ids, row records, entry records
            + distinct * param_row              # touched rows of V, entries of w
-           + B * k * 8 + B * 8                 # Q, residual out
-           + sparse_entries * 4                # slot marks
+           + B * k * 8                         # Q out
+           + sparse_entries * 16               # {position, residual} marks (+ one bit each)
            + slab + n_slabs * 8)               # hot sums, residual partials
-    cons = (sparse_entries * (4 + 4 + 16)     # marks read + reset, slot records
-            + sparse_entries * (k * 8 + 8)     # Q rows, residuals of the marked slots
+    cons = (sparse_entries * (16 + 16)        # marks read, slot records
+            + sparse_entries * k * 8           # Q rows of the marked slots
             + slab                             # slabs read back
-            + 2 * (distinct - H) * param_row)  # sparse-class rows read + written
-    fin = 2 * H * param_row + H * 4 * (k + 2) * 8 * 2  # hot rows read + written, part rows
+            + 2 * distinct * param_row)        # every touched row read + written (hot ones too)
+    fin = 0                                    # only for columns longer than a workgroup's tasks
     return {"forward": fwd, "consume": cons, "finalize": fin, "step": fwd + cons + fin,
             "distinct_columns": distinct, "sparse_entries": sparse_entries, "hot_columns": H}
 

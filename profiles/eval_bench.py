@@ -21,6 +21,7 @@ keep = synth.first_occurrences(val_mf["features"])
 
 class Hook:
     metric_name, k = "DCG", 5
+    rfm_device_evaluator = True  # its evaluate() is the reference's metric (oracle restatement)
 
     def __init__(self, rows):
         self.interaction_df = synth.interaction_frame({k: v[rows] for k, v in val_mf.items()}, val_mf["features"][rows])

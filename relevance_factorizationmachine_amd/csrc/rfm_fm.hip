@@ -1,45 +1,22 @@
-// FM path of librfm_hip.so: launch side, training plan and C-ABI entry points.
-// The kernels are in rfm_fm_kernels.hpp.
+// FM path of librfm_hip.so: launch side and C-ABI entry points of the forward, the training
+// step, its dense and touched-row gradient forms, and the fit() loop.  The kernels are in
+// rfm_fm_kernels.hpp / rfm_fm_rows.hpp, the training plan is built by rfm_fm_plan.hip
+// (layout: rfm_fm_plan.h, rfm_fm_records.h; DESIGN.md sections 3 and 4).
 //
-// Layout in HBM (all float64 unless noted):
-//   CSR of the log:   indptr int64[N+1], indices int32[nnz], values f64[nnz]
-//   parameters:       w0[1], w[n], V[n][k] row-major (the reference's NumPy layout)
-//   per-step scratch: Q[B][k] (= X_b V_old), err[B] (= y/p - sigmoid(logit))
-//   training plan (rfm_fm_plan_create, once per fit):
-//     rows  RowRec[N]   {first entry, length, label, propensity}       32 B / row
-//     ent   Entry[nnz]  {column, slot, value} in CSR order             16 B / entry
-//     columns are split in two classes
-//     HOT columns     (expected entries per batch >= hot_min_count, as many as
-//                     fit the LDS budget; side features, dense reals, top
-//                     items): Entry.slot = -1 - hot_rank.  Their V rows and w
-//                     are staged in LDS by every forward workgroup, and their
-//                     gradient is accumulated there ([H][k+2] f64, ds_add_f64);
-//                     a workgroup stores ONE slab at its end.
-//     SPARSE columns  (one-hot users / items ...): a column-major ("slot") view
-//                     of the whole training CSR restricted to these columns:
-//                     Entry.slot = column-major rank; csc_x f64, csc_col int32
-//                     per slot; slot_t int32 per slot = batch position of the
-//                     slot's row in the current batch, or -1.
-//
-// One training step (rfm_fm_step) is three launches on one stream:
-//   1. fm_forward_kernel   rows of the batch in parallel: q_t = V^T x_t, logit,
-//                          residual; writes Q, err, marks slot_t for the sparse
-//                          entries (plain stores) and adds the hot entries'
-//                          err_t x_tj [q_t, 1, x_tj] into the LDS sums.
-//   2. fm_consume_kernel   one fixed window of 64 slots per lane group: the
-//                          group reads the window's marks, accumulates
-//                          err_t x_tj [Q[t,:], 1, x_tj] over the marked slots IN
-//                          SLOT ORDER, updates V[j,:], w[j] in place for columns
-//                          wholly inside the window (it is their only writer),
-//                          leaves a stamped partial ("carry") for a column that
-//                          crosses a window border, and resets the marks.
-//                          Extra workgroups of the same launch reduce the hot
-//                          columns' slabs in block order and apply them.
-//   3. fm_finalize_kernel  crossing columns: carries summed in window order and
-//                          applied; w0 from the forward workgroups' residual sums.
-// No global float atomics.  Sparse-class sums have a fixed order (bitwise
-// reproducible); hot-class sums inside one workgroup are LDS atomics, so their
-// last bits may vary from run to run (hot_min_count < 0 turns the class off).
+// One training step (rfm_fm_step) is two launches on one stream:
+//   1. fm_forward_kernel   rows of the batch in parallel: q_t = V^T x_t, logit, residual;
+//                          writes Q, leaves {t, residual} marks + bitmap bits at the slots of
+//                          the row's sparse-class entries and adds the hot entries'
+//                          err_t x_tj [q_t, 1, x_tj] into the workgroup's LDS sums.
+//   2. fm_consume_kernel   one task (a fixed number of 64-slot bitmap words) per lane group:
+//                          lists the marked slots, accumulates err_t x_tj [Q[t,:], 1, x_tj]
+//                          IN SLOT ORDER, updates the columns inside the task in place and
+//                          combines columns that run over several tasks of the workgroup in
+//                          LDS; trailing workgroups reduce the hot columns' slabs and w0.
+//  (3. fm_finalize_kernel  only for columns longer than a whole workgroup's tasks.)
+// No global float atomics.  Sparse-class sums have a fixed order (bitwise reproducible);
+// hot-class sums inside one workgroup are LDS atomics, so their last bits may vary from run
+// to run (hot_min_count < 0 turns the class off).
 #include <algorithm>
 #include <chrono>
 #include <cmath>

@@ -250,9 +250,10 @@ def main() -> None:
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --batch-size is the GLOBAL batch, split over the GPUs "
                          "(default: weak scaling, --batch-size rows per GPU)")
-    ap.add_argument("--exchange", default="rows", choices=["rows", "dense"],
-                    help="multi-GPU gradient exchange: touched rows only (default) or the dense "
-                         "[G_V|g_w|g_w0] all-reduce the north star names as the baseline")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rows", "dense"],
+                    help="multi-GPU gradient exchange: touched rows only, or the dense [G_V|g_w|g_w0] "
+                         "all-reduce the north star names as the baseline; auto = rows when the touched "
+                         "rows of a global batch are estimated at under a quarter of the dense buffer")
     ap.add_argument("--no-direct-rccl", action="store_true",
                     help="multi-GPU dense exchange through torch.distributed instead of the C ABI's RCCL binding")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -334,7 +335,10 @@ def main() -> None:
             _lib.check(rt.lib.rfm_fm_train(
                 rt.ctx, plan.handle, *csr_ptrs, d_ids.data_ptr() + first * B * 4, B, count, *params,
                 lr, None, None, None, None, None, 0, 1e-8, None, None))
-    elif args.exchange == "rows":
+    elif args.exchange == "rows" or (args.exchange == "auto" and
+                                     4 * min(n, 2 * gB + 256) * (k + 2) * 2 < n * (k + 1)):
+        # (estimate: about two one-hot columns per row plus the side features are touched, and
+        # the records travel twice -- to the owner and back)
         # touched rows only: every rank's gradient rows go to the rank that owns the column
         # (reduce-scatter by ownership), the owner sums them in rank order and applies, and
         # the updated rows come back (all-gather) -- SURVEY.md 8e option 1

@@ -42,6 +42,10 @@ namespace rfm {
 struct FwdGeom {
   int block, grid;
 };
+#ifndef RFM_FWD_SMALL_BLOCK
+#define RFM_FWD_SMALL_BLOCK 512
+#endif
+constexpr int kSmallBlock = RFM_FWD_SMALL_BLOCK;  // threads of the one-row-per-group shape
 
 inline FwdGeom forward_geom(const rfm_ctx* ctx, int64_t n_rows, const Shape& s, bool records) {
   static const int per_cu = std::max(1, env_int("RFM_FWD_PER_CU", kBigBlock >= 1024 ? 1 : 2));
@@ -56,8 +60,8 @@ inline FwdGeom forward_geom(const rfm_ctx* ctx, int64_t n_rows, const Shape& s, 
     g.block = kBigBlock;
     g.grid = int(std::max<int64_t>(1, std::min<int64_t>(blocks_big, int64_t(ctx->n_cu) * per_cu)));
   } else {
-    g.block = 256;
-    const int gpb = 256 / s.lpr;
+    g.block = kSmallBlock;
+    const int gpb = kSmallBlock / s.lpr;
     const int64_t want = (n_rows + gpb - 1) / gpb;
     g.grid = int(std::max<int64_t>(1, std::min<int64_t>(want, int64_t(ctx->n_cu) * 8)));
   }
@@ -99,11 +103,11 @@ void launch_forward(rfm_ctx* ctx, FwdArgs a, FwdGeom geom) {
       hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), false>),  \
                          dim3(geom.grid), dim3(kBigBlock), lds, ctx->stream, a);              \
     else if (a.ent)                                                                           \
-      hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, 256, 1, true>), dim3(geom.grid),        \
-                         dim3(256), lds, ctx->stream, a);                                     \
+      hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, kSmallBlock, 1, true>), dim3(geom.grid), \
+                         dim3(kSmallBlock), lds, ctx->stream, a);                             \
     else                                                                                      \
-      hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, 256, 1, false>), dim3(geom.grid),       \
-                         dim3(256), lds, ctx->stream, a);                                     \
+      hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, kSmallBlock, 1, false>), dim3(geom.grid), \
+                         dim3(kSmallBlock), lds, ctx->stream, a);                             \
   } while (0)
   RFM_FOR_SHAPE(s, RFM_CALL_FWD);
 #undef RFM_CALL_FWD

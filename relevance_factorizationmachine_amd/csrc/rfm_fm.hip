@@ -73,6 +73,10 @@ int forward_grid(const rfm_ctx* ctx, int64_t rows, int n_factors) {
   return forward_geom(ctx, rows, shape_for(n_factors), true).grid;
 }
 
+bool forward_many_rows(const rfm_ctx* ctx, int64_t rows, int n_factors) {
+  return forward_geom(ctx, rows, shape_for(n_factors), true).block == kBigBlock;
+}
+
 inline size_t forward_lds_bytes(int block, int lpr, int rows, int n_hot, int k) {
   return size_t(block) * 8 + (size_t(block) * rows + size_t(block / lpr)) * sizeof(Entry) +
          size_t(n_hot) * size_t(k + 2) * 8;
@@ -85,9 +89,10 @@ void launch_forward(rfm_ctx* ctx, FwdArgs a, FwdGeom geom) {
       forward_lds_bytes(geom.block, s.lpr, geom.block == kBigBlock ? rows_in_flight(s.nc) : 1, a.n_hot,
                         a.k);
 
+  const bool recs = a.ent != nullptr || a.ell != nullptr;  // the plan's records
 #define RFM_CALL_FWD(L, Vv, N)                                                                \
   do {                                                                                        \
-    if (a.ent && geom.block == kBigBlock) {                                                   \
+    if (recs && geom.block == kBigBlock) {                                                    \
       static size_t lds_allowed = 64u << 10; /* per instantiation: raised on demand */       \
       if (lds > lds_allowed) {                                                                \
         RFM_HIP_CHECK(hipFuncSetAttribute(                                                    \
@@ -102,7 +107,7 @@ void launch_forward(rfm_ctx* ctx, FwdArgs a, FwdGeom geom) {
     else if (geom.block == kBigBlock)                                                         \
       hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), false>),  \
                          dim3(geom.grid), dim3(kBigBlock), lds, ctx->stream, a);              \
-    else if (a.ent)                                                                           \
+    else if (recs)                                                                            \
       hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, kSmallBlock, 1, true>), dim3(geom.grid), \
                          dim3(kSmallBlock), lds, ctx->stream, a);                             \
     else                                                                                      \
@@ -116,13 +121,13 @@ void launch_forward(rfm_ctx* ctx, FwdArgs a, FwdGeom geom) {
 
 void launch_forward(rfm_ctx* ctx, FwdArgs a) {
   if (a.n_rows <= 0) return;
-  launch_forward(ctx, a, forward_geom(ctx, a.n_rows, shape_for(a.k), a.ent != nullptr));
+  launch_forward(ctx, a, forward_geom(ctx, a.n_rows, shape_for(a.k), a.ent != nullptr || a.ell != nullptr));
 }
 
 // forward with loss: partials in ctx scratch, finished into d_out_loss
 void forward_loss(rfm_ctx* ctx, FwdArgs a, double* d_out_loss) {
   RFM_REQUIRE(a.n_rows > 0, "loss of zero rows");
-  const FwdGeom geom = forward_geom(ctx, a.n_rows, shape_for(a.k), a.ent != nullptr);
+  const FwdGeom geom = forward_geom(ctx, a.n_rows, shape_for(a.k), a.ent != nullptr || a.ell != nullptr);
   ctx->loss_partials.ensure(size_t(std::max(kMaxFwdGrid, ctx->n_cu * 8)) * sizeof(double));
   a.loss_partial = ctx->loss_partials.as<double>();
   launch_forward(ctx, a, geom);
@@ -135,7 +140,7 @@ void forward_loss(rfm_ctx* ctx, FwdArgs a, double* d_out_loss) {
 // finished later, many launches at once; returns the number of partials written
 int forward_loss_deferred(rfm_ctx* ctx, FwdArgs a, double* partial_row) {
   RFM_REQUIRE(a.n_rows > 0, "loss of zero rows");
-  const FwdGeom geom = forward_geom(ctx, a.n_rows, shape_for(a.k), a.ent != nullptr);
+  const FwdGeom geom = forward_geom(ctx, a.n_rows, shape_for(a.k), a.ent != nullptr || a.ell != nullptr);
   RFM_REQUIRE(geom.grid <= kMaxFwdGrid, "forward grid %d exceeds %d", geom.grid, kMaxFwdGrid);
   a.loss_partial = partial_row;
   launch_forward(ctx, a, geom);
@@ -200,6 +205,8 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   FwdArgs f{};
   f.ent = plan->ent.as<Entry>();
   f.rows = plan->rows.as<RowRec>();
+  f.ell = plan->ell.as<char>();
+  f.ell_stride = plan->ell_stride;
   f.row_ids = d_row_ids;
   f.n_rows = batch;
   f.w0 = d_w0;
@@ -617,6 +624,8 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
         FwdArgs f{};
         f.ent = plan->ent.as<Entry>();
         f.rows = plan->rows.as<RowRec>();
+        f.ell = plan->ell.as<char>();
+        f.ell_stride = plan->ell_stride;
         f.row_ids = ids;
         f.n_rows = batch;
         f.w0 = d_w0;

@@ -115,6 +115,8 @@ struct FwdArgs {
   // the log: either the plan's records (training) ...
   const Entry* ent;
   const RowRec* rows;
+  const char* ell;       // ... in their padded form when every row fits one round: row blocks
+  int64_t ell_stride;    //     {EllHdr, Entry[LPR]} of this many bytes (then ent / rows are null)
   // ... or the caller's CSR arrays (+ labels / propensities when a loss is asked for)
   const int64_t* indptr;
   const int32_t* indices;
@@ -216,9 +218,24 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
 #pragma unroll
       for (int i = 0; i < R; ++i) r[i] = a.row_ids[r[i]];
     }
+    const bool ell = REC && a.ell != nullptr;  // uniform
+    Entry e0[R];  // ell: the row's entry of this lane, loaded next to the row's head
+    if (ell) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const char* blk = a.ell + r[i] * a.ell_stride;
+        const EllHdr hd = *reinterpret_cast<const EllHdr*>(blk);
+        e0[i] = reinterpret_cast<const Entry*>(blk + sizeof(EllHdr))[l];
+        p0[i] = 0;
+        len[i] = valid[i] ? hd.len : 0;
+        yy[i] = hd.y;
+        pp[i] = hd.p;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      if (REC) {
+      if (ell) {
+      } else if (REC) {
         const RowRec rec = a.rows[r[i]];
         p0[i] = EntryOff(rec.begin);
         len[i] = valid[i] ? int(rec.len) : 0;
@@ -264,7 +281,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
         const int my = pb + l;
         // clamp into the row's own entries (entry 0 of the log for an empty row)
         const EntryOff at = len[i] > 0 ? p0[i] + min(my, len[i] - 1) : 0;
-        if (REC) {
+        if (ell) {
+          e[i] = e0[i];  // one round; the block is padded with the row's last entry
+        } else if (REC) {
           e[i] = a.ent[at];
         } else {
           e[i].col = a.indices[at];
@@ -366,7 +385,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
         Entry em[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          if (maxlen > LPR) {
+          if (maxlen > LPR) {  // (never in the padded form)
             em[i] = a.ent[len[i] > 0 ? p0[i] + min(pb + l, len[i] - 1) : 0];
             if (pb + l >= len[i]) em[i] = Entry{0, 0, 0.0};
             ebuf[i * LPR + l] = em[i];

@@ -15,6 +15,8 @@ struct rfm_fm_plan {
   int32_t n_split_short = 0, n_split_long = 0, n_parts = 0, n_hot = 0;
   int64_t step = 0;  // stamps the partial rows of a step
   int32_t fwd_grid_max = 0;  // forward workgroups of a max_batch step (= hot-sum slabs)
+  rfm::DevBuf ell;            // padded row blocks (every row <= lanes-per-group entries), else empty
+  int64_t ell_stride = 0;
   rfm::DevBuf ent, rows, slot_t, slot_bits, slots, tasks, split, parts, Q, err, hot_cols, hot_slab,
       err_partial;
   rfm::DevBuf loss_rows;  // rfm_fm_train: per-workgroup loss partials of a run of iterations
@@ -27,7 +29,7 @@ struct rfm_fm_plan {
   rfm::DevBuf ids_seen, ids_flags;  // RFM_CHECK_IDS=1: validation of the steps' row ids
   int32_t ids_stamp = 0;
   size_t device_bytes() const {
-    return ent.bytes + rows.bytes + slot_t.bytes + slot_bits.bytes + slots.bytes + tasks.bytes +
+    return ell.bytes + ent.bytes + rows.bytes + slot_t.bytes + slot_bits.bytes + slots.bytes + tasks.bytes +
            split.bytes + parts.bytes + Q.bytes + err.bytes + hot_cols.bytes + hot_slab.bytes +
            err_partial.bytes;
   }
@@ -54,5 +56,7 @@ inline int env_int(const char* name, int dflt) {
 
 // workgroups the training forward launches for `rows` batch rows (defined in rfm_fm.hip)
 int forward_grid(const rfm_ctx* ctx, int64_t rows, int n_factors);
+// whether that forward takes the many-rows-in-flight shape
+bool forward_many_rows(const rfm_ctx* ctx, int64_t rows, int n_factors);
 
 }  // namespace rfm

@@ -19,6 +19,13 @@ struct RowRec {      // one row of the training log, 32 B
   double y;          // label
   double p;          // propensity (already raised to pow_used by the loader)
 };
+struct EllHdr {      // head of a row block of the padded form of the log (rows of <= LPR entries):
+  int32_t len;       // {EllHdr, Entry[LPR]} at a fixed stride, so that the row's record AND its
+  int32_t pad;       // entries are one dependent load behind the row id, not two; 32 B
+  double y;
+  double p;
+  double pad2;
+};
 struct SlotRec {  // one slot of the column-major view, 16 B
   double x;       // feature value
   int32_t col;    // feature column

@@ -338,7 +338,7 @@ int32_t rfm_fm_forward(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_i
                        int64_t n_features, int32_t n_factors, double* d_out_pred) {
   return guarded([&] {
     RFM_REQUIRE(ctx, "null ctx");
-    RFM_REQUIRE(n_rows >= 0 && n_features >= 1, "bad shape");
+    RFM_REQUIRE(n_rows >= 0 && n_rows < (int64_t(1) << 31) && n_features >= 1, "bad shape");
     if (n_rows == 0) return;  // nothing to score (empty inputs carry null pointers)
     RFM_REQUIRE(d_indptr && d_w0 && d_w && d_V && d_out_pred, "null pointer");
     RFM_REQUIRE(d_indices && d_values, "null CSR arrays");
@@ -376,7 +376,7 @@ int32_t rfm_fm_forward_loss(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t
     RFM_REQUIRE(ctx && d_indptr && d_indices && d_values && d_y && d_pscore && d_w0 && d_w &&
                     d_V && d_out_loss,
                 "null pointer");
-    RFM_REQUIRE(n_rows >= 1 && n_features >= 1, "bad shape");
+    RFM_REQUIRE(n_rows >= 1 && n_rows < (int64_t(1) << 31) && n_features >= 1, "bad shape");
     FwdArgs f = forward_args(d_indptr, d_indices, d_values, d_row_ids, n_rows, d_w0, d_w, d_V,
                              n_factors);
     f.y = d_y;

@@ -201,7 +201,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
 
   for (int64_t base = int64_t(blockIdx.x) * (GPB * R); base < a.n_rows;
        base += int64_t(gridDim.x) * (GPB * R)) {
-    int64_t t[R], r[R];
+    int64_t t[R];
+    int32_t r[R];  // rows of a log (or of a batch) fit 31 bits
     // entry offsets: the plan checks that they fit 31 bits; the caller's CSR is taken as it is
     using EntryOff = typename std::conditional<REC, int32_t, int64_t>::type;
     EntryOff p0[R];
@@ -212,18 +213,31 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
     for (int i = 0; i < R; ++i) {
       t[i] = base + i * GPB + g;
       valid[i] = t[i] <= last_row;
-      r[i] = valid[i] ? t[i] : last_row;
+      r[i] = int32_t(valid[i] ? t[i] : last_row);
     }
     if (a.row_ids) {  // uniform: the R loads stay in one block and overlap
 #pragma unroll
       for (int i = 0; i < R; ++i) r[i] = a.row_ids[r[i]];
+    }
+    // the workgroup's NEXT trip: its row ids now, and (below, under the hot pass) a touch of
+    // its row blocks, so that the next trip's first two dependent loads find their lines
+    // on chip instead of waiting for memory
+    int32_t nxt[R];
+    const int64_t nbase = base + int64_t(gridDim.x) * (GPB * R);
+    const bool warm = REC && BLOCK == kBigBlock && a.ell != nullptr && a.row_ids && nbase < a.n_rows;
+    if (warm) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const int64_t nt = nbase + i * GPB + g;
+        nxt[i] = a.row_ids[nt <= last_row ? nt : last_row];
+      }
     }
     const bool ell = REC && a.ell != nullptr;  // uniform
     Entry e0[R];  // ell: the row's entry of this lane, loaded next to the row's head
     if (ell) {
 #pragma unroll
       for (int i = 0; i < R; ++i) {
-        const char* blk = a.ell + r[i] * a.ell_stride;
+        const char* blk = a.ell + int64_t(r[i]) * a.ell_stride;
         const EllHdr hd = *reinterpret_cast<const EllHdr*>(blk);
         e0[i] = reinterpret_cast<const Entry*>(blk + sizeof(EllHdr))[l];
         p0[i] = 0;
@@ -377,6 +391,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
       }
     }
 
+    int32_t touched[R];
+    if (warm) {
+#pragma unroll
+      for (int i = 0; i < R; ++i)  // lane l touches the 16 bytes of its own entry; lane 0's line holds the head
+        touched[i] = *reinterpret_cast<const int32_t*>(a.ell + int64_t(nxt[i]) * a.ell_stride +
+                                                      (l == 0 ? 0 : int(sizeof(EllHdr)) + 16 * l));
+    }
     if (REC && (a.slot_mark || (H > 0 && RFM_KEEP(a, 32)))) {
       // after the residual is known: marks of the sparse-class entries, and the hot
       // entries' err * x * [q, 1, x] into the workgroup's LDS sums.  A single round (rows
@@ -445,6 +466,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
           }
         }
       }
+    }
+    if (warm) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) asm volatile("" ::"v"(touched[i]));  // keep the touches alive
     }
   }
 

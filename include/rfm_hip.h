@@ -141,10 +141,10 @@ int32_t rfm_fm_plan_create_device(rfm_ctx* ctx, const int64_t* d_indptr, const i
                                   int32_t n_factors, int64_t max_batch, int32_t hot_min_count,
                                   rfm_fm_plan** out);
 int32_t rfm_fm_plan_destroy(rfm_fm_plan* plan);
-/* h_out8[0]=slot windows, [1]=columns crossing a window border, [2]=hot
- * columns, [3]=nnz, [4]=device bytes owned by the plan, [5]=forward workgroups
- * of a max_batch step (= hot-sum slabs per step), [6]=slots of the sparse
- * class, [7]=reserved (0) */
+/* h_out8[0]=tasks of the gradient launch, [1]=columns longer than a workgroup's
+ * tasks (split), [2]=hot columns, [3]=nnz, [4]=device bytes owned by the plan,
+ * [5]=forward workgroups of a max_batch step (= hot-sum slabs per step), [6]=slots
+ * of the sparse class (padded to whole tasks), [7]=64-slot bitmap words per task */
 int32_t rfm_fm_plan_info(const rfm_fm_plan* plan, int64_t* h_out8);
 /* the hot columns (ascending), h_out[0 .. info[2]); capacity = room in h_out */
 int32_t rfm_fm_plan_hot_columns(const rfm_fm_plan* plan, int32_t* h_out, int32_t capacity);

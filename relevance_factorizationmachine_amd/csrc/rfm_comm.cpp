@@ -27,13 +27,23 @@ const Rccl& rccl() {
   static Rccl api = [] {
     Rccl a;
     // an RCCL the process has already mapped (PyTorch's own, bound to PyTorch's HIP runtime)
-    // is the one to use: a second copy would bring a second runtime with it
-    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    // is the one to use: a second copy would bring a second HIP runtime with it, which knows
+    // nothing of the caller's allocations.  Only a process without one (no PyTorch) loads
+    // the system's; RFM_RCCL_PATH names a specific library.
+    void* h = nullptr;
+    if (const char* path = getenv("RFM_RCCL_PATH")) h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) rfm::fail(RFM_ERR_INTERNAL, "cannot load librccl.so: %s", dlerror());
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    const bool torch_here = dlopen("libtorch_hip.so", RTLD_NOW | RTLD_NOLOAD) != nullptr ||
+                            dlopen("libtorch_cpu.so", RTLD_NOW | RTLD_NOLOAD) != nullptr;
+    if (!h && !torch_here) {
+      h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!h)
+      rfm::fail(RFM_ERR_INTERNAL, "cannot bind RCCL (%s)",
+                torch_here ? "PyTorch is loaded but its librccl is not mapped" : dlerror());
     a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));

@@ -43,7 +43,7 @@ struct FwdGeom {
   int block, grid;
 };
 #ifndef RFM_FWD_SMALL_BLOCK
-#define RFM_FWD_SMALL_BLOCK 512
+#define RFM_FWD_SMALL_BLOCK 256
 #endif
 constexpr int kSmallBlock = RFM_FWD_SMALL_BLOCK;  // threads of the one-row-per-group shape
 

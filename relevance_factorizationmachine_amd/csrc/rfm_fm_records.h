@@ -52,7 +52,4 @@ struct SplitCol {      // a sparse-class column longer than a whole workgroup's 
   int32_t pad;
 };
 
-// slab ranges a hot column's reduction is cut into (one workgroup each)
-constexpr int kHotParts = 4;
-
 }  // namespace rfm

@@ -764,3 +764,22 @@ def test_plan_builders_agree_and_reject_malformed_logs(rfm):
     # a log without entries still gives a plan (rows score sigmoid(w0))
     empty = host_plan(np.zeros(4, np.int64), np.zeros(1, np.int32), np.zeros(1), n_rows=3, n_cols=5)
     rt.lib.rfm_fm_plan_destroy(empty)
+
+
+def test_deterministic_switch_gives_bitwise_reproducible_fits(rfm):
+    """model.deterministic = True (hot_min_count = -1): every sum has a fixed order, two fits are
+    equal bit for bit; the default (hot columns summed with LDS atomics) agrees to ~1e-13."""
+    pkg = rfm[0]
+    train, val = synth.make_log("kuairec_small", "FM", "IPS", seed=0)
+    kw = dict(estimator="IPS", n_epochs=4, n_factors=16, lr=9e-6, batch_size=2000, seed=12345,
+              n_features=train["features"].shape[1])
+    fits = []
+    for det in (True, True, False):
+        m = pkg.FactorizationMachines(**kw)
+        m.deterministic = det
+        tr, va = m.fit(train, val)
+        fits.append((m.V(), m.w(), tr, va))
+    np.testing.assert_array_equal(fits[0][0], fits[1][0])
+    np.testing.assert_array_equal(fits[0][1], fits[1][1])
+    assert fits[0][2] == fits[1][2] and fits[0][3] == fits[1][3]
+    assert rel_err(fits[2][0], fits[0][0]) < 1e-12 and rel_err(fits[2][2], fits[0][2]) < 1e-12

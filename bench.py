@@ -452,6 +452,12 @@ def main() -> None:
         run(W, K)
         _lib.check(rt.lib.rfm_profile_end(rt.ctx, ms, cnt))
         avg = [ms[i] / max(cnt[i], 1) for i in range(3)]
+        info = plan.info()
+        # a plan without split columns launches no finalize kernel: the third interval is then
+        # two back-to-back events, i.e. what one event pair itself costs on this stream
+        event_gap_ms = None
+        if info["split_columns"] == 0:
+            event_gap_ms, avg[2] = avg[2], 0.0
         fwd_b, upd_b = algorithmic_bytes(z, k)
         alg = [fwd_b * B, upd_b * B, 0.0]
         dom = int(np.argmax(avg))
@@ -459,7 +465,6 @@ def main() -> None:
         step_ms = 1e3 * elapsed / K  # the driver-visible step (median region), not the event sum
         whole_alg = (fwd_b + upd_b) * B
         whole_achieved = whole_alg / (step_ms * 1e-3) / 1e9
-        info = plan.info()
         comp = compulsory_bytes(X, ids[W][:B], k, plan.hot_columns(), info["forward_workgroups"])
         comp_keys = ["forward", "consume", "finalize"]
 
@@ -497,6 +502,7 @@ def main() -> None:
             "frac_compulsory": comp[comp_keys[dom]] / (avg[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "avg_launch_ms": avg[dom],
             "all_kernels_avg_ms": dict(zip(STEP_KERNELS, avg)),
+            "event_pair_gap_ms": event_gap_ms,
             "whole_step": {
                 "ms": step_ms, "event_sum_ms": ms[3] / max(cnt[3], 1),
                 "algorithmic_bytes": whole_alg, "achieved": whole_achieved,
@@ -520,6 +526,7 @@ def main() -> None:
             if B != 2000:
                 # the reference's own batch size (conf/setting/kuairec.yaml:52)
                 plan2 = FmPlan(rt, csr, y, p, k, 2000)
+                plan2_split = plan2.info()["split_columns"] > 0
                 ids2 = rt.upload(sample_batches(n_train, 2000, 0, 220))
 
                 def run2(first, count):
@@ -540,7 +547,9 @@ def main() -> None:
                 _lib.check(rt.lib.rfm_profile_end(rt.ctx, ms, cnt))
                 out["extra"]["batch_2000"] = {
                     "value": 2000 / dt, "unit": "examples/s", "ms_per_step": 1e3 * dt,
-                    "kernels_avg_ms": dict(zip(STEP_KERNELS, [ms[i] / max(cnt[i], 1) for i in range(3)])),
+                    "kernels_avg_ms": dict(zip(STEP_KERNELS, [
+                        ms[i] / max(cnt[i], 1) if i < 2 or plan2_split else 0.0 for i in range(3)])),
+                    "event_pair_gap_ms": None if plan2_split else ms[2] / max(cnt[2], 1),
                     "algorithmic_frac": (fwd_b + upd_b) * 2000 / dt / 1e9 / HBM_PEAK_GBS}
                 plan2.close()
             # variant (A): fit() exactly as the reference runs it (src/fm.py:71-102)

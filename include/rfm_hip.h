@@ -126,7 +126,8 @@ int32_t rfm_fm_forward_loss(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t
  * indices int32, values / labels / propensities float64).  Both reject an indptr
  * that is not monotone, a column index outside 0..n_features-1 and a row that
  * names a column twice (RFM_ERR_BAD_ARG).
- * max_batch bounds the batch size of later steps.  hot_min_count: a column
+ * max_batch bounds the batch size of later steps (max_batch * n_factors < 2^31).
+ * hot_min_count: a column
  * whose expected number of entries per batch (its training frequency *
  * max_batch / n_rows) reaches this value is accumulated on chip by the forward
  * workgroups instead of through its column list (0 = library default,

@@ -93,16 +93,26 @@ void launch_forward(rfm_ctx* ctx, FwdArgs a, FwdGeom geom) {
 #define RFM_CALL_FWD(L, Vv, N)                                                                \
   do {                                                                                        \
     if (recs && geom.block == kBigBlock) {                                                    \
-      static size_t lds_allowed = 64u << 10; /* per instantiation: raised on demand */       \
+      static size_t lds_allowed = 64u << 10; /* per instantiation pair: raised on demand */  \
       if (lds > lds_allowed) {                                                                \
         RFM_HIP_CHECK(hipFuncSetAttribute(                                                    \
             reinterpret_cast<const void*>(                                                    \
-                &fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), true>),            \
+                &fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), true, false>),     \
+            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));                           \
+        RFM_HIP_CHECK(hipFuncSetAttribute(                                                    \
+            reinterpret_cast<const void*>(                                                    \
+                &fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), true, true>),      \
             hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));                           \
         lds_allowed = lds;                                                                    \
       }                                                                                       \
-      hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), true>),   \
-                         dim3(geom.grid), dim3(kBigBlock), lds, ctx->stream, a);              \
+      if (a.ell)                                                                              \
+        hipLaunchKernelGGL(                                                                   \
+            (fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), true, true>),          \
+            dim3(geom.grid), dim3(kBigBlock), lds, ctx->stream, a);                           \
+      else                                                                                    \
+        hipLaunchKernelGGL(                                                                   \
+            (fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), true, false>),         \
+            dim3(geom.grid), dim3(kBigBlock), lds, ctx->stream, a);                           \
     }                                                                                         \
     else if (geom.block == kBigBlock)                                                         \
       hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), false>),  \

@@ -165,7 +165,8 @@ struct FwdArgs {
 // REC: read the training plan's records (RowRec / Entry); otherwise the
 // caller's CSR arrays.
 // LDS (dynamic): red[BLOCK] f64 | entry buffer [BLOCK/LPR][R*LPR+1] Entry | hot sums [H][k+2] f64
-template <int LPR, int VEC, int NC, int BLOCK, int R, bool REC>
+// ELL (with REC): the records come as padded row blocks (a.ell).
+template <int LPR, int VEC, int NC, int BLOCK, int R, bool REC, bool ELL = false>
 __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)) void fm_forward_kernel(
     FwdArgs a) {
   constexpr int GPB = BLOCK / LPR;  // lane groups per block
@@ -224,7 +225,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
     // on chip instead of waiting for memory
     int32_t nxt[R];
     const int64_t nbase = base + int64_t(gridDim.x) * (GPB * R);
-    const bool warm = REC && BLOCK == kBigBlock && a.ell != nullptr && a.row_ids && nbase < a.n_rows;
+    constexpr bool ell = REC && ELL;
+    const bool warm = ell && BLOCK == kBigBlock && a.row_ids && nbase < a.n_rows;
+    int32_t* parked = reinterpret_cast<int32_t*>(red);  // (red is only used after the trips)
     if (warm) {
 #pragma unroll
       for (int i = 0; i < R; ++i) {
@@ -232,7 +235,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
         nxt[i] = a.row_ids[nt <= last_row ? nt : last_row];
       }
     }
-    const bool ell = REC && a.ell != nullptr;  // uniform
     Entry e0[R];  // ell: the row's entry of this lane, loaded next to the row's head
     if (ell) {
 #pragma unroll
@@ -273,6 +275,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
     int maxlen = len[0];
 #pragma unroll
     for (int i = 1; i < R; ++i) maxlen = max(maxlen, len[i]);
+    if (warm) {
+      // the next trip's ids arrived with this trip's heads; they wait in LDS while the
+      // gathers need every register
+#pragma unroll
+      for (int i = 0; i < R; ++i)
+        if (l == 0) parked[i * GPB + g] = nxt[i];
+    }
 
     double q[R][NC][VEC];
     double s2[R], lin[R], err[R];
@@ -350,6 +359,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
       }
     }
 
+    if (warm) {  // back from LDS (same wave wrote them): the gathers' registers are free again
+#pragma unroll
+      for (int i = 0; i < R; ++i) nxt[i] = parked[i * GPB + g];
+    }
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       if (len[i] == 0) {  // an empty row scores sigmoid(w0) whatever its padding gathered
@@ -371,14 +384,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
       err[i] = valid[i] ? yy[i] / pp[i] - pred : 0.0;
       if (valid[i]) {
         if (a.out_Q && RFM_KEEP(a, 2)) {
-          double* qrow = a.out_Q + t[i] * k;
+          // (Q belongs to a plan: max_batch * k fits 31 bits, checked where it is made)
+          const uint32_t qoff = uint32_t(t[i]) * uint32_t(k);
 #pragma unroll
           for (int c = 0; c < NC; ++c) {
             if (fok[c]) {
               Pack<VEC> pq;
 #pragma unroll
               for (int v = 0; v < VEC; ++v) pq.v[v] = q[i][c][v];
-              pq.store(qrow + fo[c]);
+              pq.store(a.out_Q + (qoff + uint32_t(fo[c])));
             }
           }
         }

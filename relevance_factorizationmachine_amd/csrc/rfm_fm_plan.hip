@@ -133,6 +133,9 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
                         int32_t hot_min_count) {
   RFM_REQUIRE(ctx && d_indptr && d_y && d_pscore, "null pointer");
   RFM_REQUIRE(n_rows >= 1 && n_features >= 1 && max_batch >= 1, "bad shape");
+  RFM_REQUIRE(max_batch * int64_t(n_factors) < (int64_t(1) << 31),
+              "max_batch * n_factors = %lld does not fit the 31-bit offsets of the batch's Q rows",
+              (long long)(max_batch * int64_t(n_factors)));
   RFM_REQUIRE(n_rows < (int64_t(1) << 31), "too many rows");
   RFM_REQUIRE(n_features < (int64_t(1) << 31) - 2, "n_features too large");
   RFM_HIP_CHECK(hipSetDevice(ctx->device));

@@ -50,7 +50,12 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--child":  # measure in this process (for rocprofv3 -- python3 ...)
         exec(compile(CHILD % {"root": ROOT}, "ablate_child", "exec"), {"__name__": "__main__"})
         return
-    specs = [a for a in sys.argv[1:] if "=" in a or a.isidentifier()]
+    argv = sys.argv[1:]
+    if "--batch" in argv:  # same as ABL_BATCH in the environment
+        at = argv.index("--batch")
+        os.environ["ABL_BATCH"] = argv[at + 1]
+        del argv[at:at + 2]
+    specs = [a for a in argv if "=" in a or a.isidentifier()]
     for spec in specs:
         name, _, rest = spec.partition("=")
         env = dict(os.environ)

@@ -147,6 +147,11 @@ int32_t rfm_fm_plan_destroy(rfm_fm_plan* plan);
  * [5]=forward workgroups of a max_batch step (= hot-sum slabs per step), [6]=slots
  * of the sparse class (padded to whole tasks), [7]=64-slot bitmap words per task */
 int32_t rfm_fm_plan_info(const rfm_fm_plan* plan, int64_t* h_out8);
+/* how the plan keeps the log for the forward: h_out4[0]=1 if as padded row blocks (every
+ * row fits one round of a lane group and max_batch asks for the many-rows shape), else 0 =
+ * row + entry records; [1]=bytes of a row block (0 if none); [2]=lanes per row of this
+ * factor count; [3]=entries of the longest row */
+int32_t rfm_fm_plan_layout(const rfm_fm_plan* plan, int32_t* h_out4);
 /* the hot columns (ascending), h_out[0 .. info[2]); capacity = room in h_out */
 int32_t rfm_fm_plan_hot_columns(const rfm_fm_plan* plan, int32_t* h_out, int32_t capacity);
 

@@ -88,6 +88,7 @@ SIGNATURES = {
     "rfm_fm_plan_create_device": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _i32, C.POINTER(_vp)],
     "rfm_fm_plan_destroy": [_vp],
     "rfm_fm_plan_info": [_vp, _vp],
+    "rfm_fm_plan_layout": [_vp, _vp],
     "rfm_fm_plan_hot_columns": [_vp, _vp, _i32],
     "rfm_fm_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f64],
     "rfm_fm_grad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],

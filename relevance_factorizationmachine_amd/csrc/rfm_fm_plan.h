@@ -13,6 +13,7 @@ struct rfm_fm_plan {
   int32_t n_task_blocks = 0;  // workgroups of fm_consume_kernel that process tasks
   int32_t task_words = 1;     // 64-slot words per task
   int32_t n_split_short = 0, n_split_long = 0, n_parts = 0, n_hot = 0;
+  int32_t max_row_len = 0;  // entries of the longest row of the log
   int64_t step = 0;  // stamps the partial rows of a step
   int32_t fwd_grid_max = 0;  // forward workgroups of a max_batch step (= hot-sum slabs)
   rfm::DevBuf ell;            // padded row blocks (every row <= lanes-per-group entries), else empty

@@ -338,6 +338,7 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
   // one-row shape of small batches measured 0.9 us slower with them, so plans for small
   // batches keep the plain records); the plain records are then not kept
   const int64_t max_len = h_flags[3];
+  plan->max_row_len = int32_t(max_len);
   if (nnz > 0 && max_len <= shp.lpr && forward_many_rows(ctx, max_batch, n_factors) &&
       env_int("RFM_NO_ELL", 0) == 0) {
     plan->ell_stride = int64_t(sizeof(EllHdr)) + int64_t(shp.lpr) * int64_t(sizeof(Entry));
@@ -437,6 +438,16 @@ int32_t rfm_fm_plan_info(const rfm_fm_plan* plan, int64_t* h_out8) {
     h_out8[5] = plan->fwd_grid_max;
     h_out8[6] = plan->n_slots;
     h_out8[7] = plan->task_words;
+  });
+}
+
+int32_t rfm_fm_plan_layout(const rfm_fm_plan* plan, int32_t* h_out4) {
+  return guarded([&] {
+    RFM_REQUIRE(plan && h_out4, "null pointer");
+    h_out4[0] = plan->ell.p ? 1 : 0;
+    h_out4[1] = plan->ell.p ? int32_t(plan->ell_stride) : 0;
+    h_out4[2] = rfm::shape_for(plan->k).lpr;
+    h_out4[3] = plan->max_row_len;
   });
 }
 

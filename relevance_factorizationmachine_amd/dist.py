@@ -103,6 +103,16 @@ def init_direct_rccl(rt, world: int, rank: int) -> bool:
         return False
     buf = (C.c_uint8 * 128).from_buffer_copy(box[0])
     _lib.check(rt.lib.rfm_comm_init(rt.ctx, world, rank, buf))
+    # known-answer all-reduce before anything depends on the communicator: sum of the ranks'
+    # numbers (a wrong enum value or ABI mismatch shows here, not as a diverged model)
+    import torch
+
+    probe = torch.full((3,), float(rank + 1), dtype=torch.float64, device=rt.device)
+    _lib.check(rt.lib.rfm_allreduce_sum(rt.ctx, probe.data_ptr(), 3))
+    rt.sync()
+    want = world * (world + 1) / 2
+    if not bool((probe == want).all().item()):
+        raise RuntimeError(f"RCCL all-reduce self-test: got {probe.tolist()}, want {want}")
     return True
 
 

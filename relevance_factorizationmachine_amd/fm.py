@@ -48,6 +48,12 @@ class FmPlan:
         return dict(zip(("tasks", "split_columns", "hot_columns", "nnz", "device_bytes",
                          "forward_workgroups", "slots", "task_words"), (int(v) for v in out)))
 
+    def layout(self) -> dict:
+        out = np.zeros(4, dtype=np.int32)
+        _lib.check(self.rt.lib.rfm_fm_plan_layout(self.handle, out.ctypes.data))
+        return dict(zip(("row_blocks", "row_block_bytes", "lanes_per_row", "longest_row"),
+                        (int(v) for v in out)))
+
     def hot_columns(self) -> np.ndarray:
         out = np.zeros(max(self.info()["hot_columns"], 1), dtype=np.int32)
         _lib.check(self.rt.lib.rfm_fm_plan_hot_columns(self.handle, out.ctypes.data, out.shape[0]))
@@ -134,6 +140,7 @@ class FactorizationMachines(PointwiseBaseRecommender):
         vp = rt.upload(np.asarray(val["pscores"]), dtype=np.float64)
         plan = FmPlan(rt, tr, y, p, self.n_factors, self.batch_size,
                       -1 if self.deterministic else self.hot_min_count)
+        self.plan_info = dict(plan.info(), **plan.layout())  # (what the last fit trained with)
         tl = rt.empty((self.n_epochs,), y.dtype)
         vl = rt.empty((self.n_epochs,), y.dtype)
         # an empty validation set: the reference's mean over no rows is nan (src/base.py:61)

@@ -249,6 +249,53 @@ def test_fm_fit_full_chip_batches(rfm, k, density, dense_cols, hot):
     assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
 
 
+def _bounded_log(rng, n_rows, n_cols, max_len, dense_cols):
+    """Rows of 0..max_len entries (a few empty), `dense_cols` columns in (almost) every row."""
+    lens = rng.integers(0, max_len + 1, size=n_rows)
+    lens[rng.integers(0, n_rows, size=5)] = 0
+    lens[rng.integers(0, n_rows, size=5)] = max_len
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    cols = np.empty(indptr[-1], dtype=np.int32)
+    for r in range(n_rows):
+        m = lens[r]
+        if m:
+            d = min(dense_cols, m)
+            rest = rng.choice(np.arange(dense_cols, n_cols), size=m - d, replace=False) if m > d else []
+            cols[indptr[r]: indptr[r + 1]] = np.sort(np.concatenate([np.arange(d), rest]).astype(np.int32))
+    X = csr_matrix((rng.standard_normal(indptr[-1]), cols, indptr), shape=(n_rows, n_cols))
+    y = (rng.random(n_rows) < 0.5).astype(np.int64)
+    p = rng.uniform(0.1, 1.0, size=n_rows) ** 0.5
+    return {"features": X, "labels": y, "pscores": p}
+
+
+@pytest.mark.parametrize("hot", [0, -1])
+@pytest.mark.parametrize("k,max_len,n_rows", [(4, 4, 140_000), (8, 4, 72_000), (16, 8, 72_000), (30, 16, 40_000),
+                                              (64, 20, 24_000), (97, 33, 12_000), (128, 64, 12_000),
+                                              (200, 40, 12_000), (7, 5, 72_000), (33, 30, 12_000)])
+def test_fm_fit_padded_row_blocks(rfm, k, max_len, n_rows, hot):
+    """Logs whose longest row fits one round of a lane group, at batches that take the
+    many-rows shape: the plan keeps padded row blocks and the forward reads them (every
+    lanes-per-row count, one and several factor chunks per lane, empty and full rows, a
+    last partial trip).  Two iterations against the oracle."""
+    pkg = rfm[0]
+    rng = np.random.default_rng(31 * k + hot)
+    n_cols = 150
+    batch = n_rows - 1234
+    train = _bounded_log(rng, n_rows, n_cols, max_len, 2)
+    val = _bounded_log(rng, 300, n_cols, max_len, 2)
+    lr = 2e-6
+    model = _fm(pkg, n_factors=k, n_features=n_cols, lr=lr, batch_size=batch, n_epochs=2, seed=5)
+    model.hot_min_count = hot
+    tr, va = model.fit(train, val)
+    assert model.plan_info["row_blocks"] == 1 and model.plan_info["longest_row"] == max_len
+    assert model.plan_info["row_block_bytes"] == 32 + 16 * model.plan_info["lanes_per_row"]
+    ref = cpu_ref.fm_fit(train, val, n_epochs=2, n_factors=k, lr=lr, batch_size=batch, seed=5)
+    assert rel_err(model.V(), ref["V"]) < TIGHT
+    assert rel_err(model.w(), ref["w"]) < TIGHT
+    assert rel_err(model.w0(), ref["w0"]) < TIGHT
+    assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
+
+
 def test_non_canonical_csr_inputs(rfm):
     """CSR as SciPy allows it: duplicate column entries inside a row (SciPy sums them
     before squaring -- X.power(2) de-duplicates -- and so must we), unsorted indices,

@@ -129,15 +129,19 @@ class FactorizationMachines(PointwiseBaseRecommender):
             return [], []
         # batch selection: resample(..., random_state=epoch) (src/fm.py:72-79), sampled on the
         # host chunk by chunk while the GPU trains on the chunk before
-        id_stream = BatchIdStream(rt, n_rows, self.batch_size, self.n_epochs)
+        id_stream = BatchIdStream(rt, n_rows, self.batch_size, self.n_epochs, need_host=False)
 
         # a log that is already in HBM (features.assemble / load_csr_to_device) is used as it is
-        tr = X if isinstance(X, DeviceCSR) else DeviceCSR(rt, X)
-        y = rt.upload(np.asarray(train["labels"]), dtype=np.float64)
-        p = rt.upload(np.asarray(train["pscores"]), dtype=np.float64)
-        va = val["features"] if isinstance(val["features"], DeviceCSR) else DeviceCSR(rt, val["features"])
-        vy = rt.upload(np.asarray(val["labels"]), dtype=np.float64)
-        vp = rt.upload(np.asarray(val["pscores"]), dtype=np.float64)
+        # (device copies of the split are remembered per device: the drivers fit several models
+        # on it; an array edited in place is uploaded again -- CsrCache._fingerprint)
+        keep = rt.remember_splits
+        tr = X if isinstance(X, DeviceCSR) else (rt.log_cache().get(X) if keep else DeviceCSR(rt, X))
+        y = rt.upload_cached(train["labels"], np.float64)
+        p = rt.upload_cached(train["pscores"], np.float64)
+        va = (val["features"] if isinstance(val["features"], DeviceCSR) else
+              (rt.log_cache().get(val["features"]) if keep else DeviceCSR(rt, val["features"])))
+        vy = rt.upload_cached(val["labels"], np.float64)
+        vp = rt.upload_cached(val["pscores"], np.float64)
         plan = FmPlan(rt, tr, y, p, self.n_factors, self.batch_size,
                       -1 if self.deterministic else self.hot_min_count)
         self.plan_info = dict(plan.info(), **plan.layout())  # (what the last fit trained with)
@@ -176,7 +180,7 @@ class FactorizationMachines(PointwiseBaseRecommender):
                     loop = EvalLoop(rt, frame, self.evaluator, self.estimator, self.n_epochs)
             for first, host_ids, dev_ids in id_stream.chunks():
                 chunk["first"], chunk["ids"] = first, dev_ids
-                count = host_ids.shape[0]
+                count = dev_ids.shape[0]
                 if self.evaluator is None:
                     run(first, count)
                 elif frame is None:

@@ -29,8 +29,20 @@ def ptr(t) -> Optional[int]:
     return t.data_ptr()
 
 
+def _sample_hash(arr: np.ndarray) -> int:
+    """Hash of both ends and of 16 384 evenly spaced elements of a 1-D array: what the upload
+    caches compare before they trust a device copy (an in-place edit of a whole array, or of
+    any sampled element, shows; a single edited element in between does not)."""
+    step = max(1, len(arr) // 16384)
+    return hash(np.concatenate([arr[:64], arr[::step], arr[-64:]]).tobytes())
+
+
 class Runtime:
     """One librfm context on one GPU, bound to torch's current stream."""
+
+    # fit() keeps the device copies of the split it was given (features, labels,
+    # propensities) for the next fit on the same objects; False = upload every time
+    remember_splits = True
 
     _instances: Dict[int, "Runtime"] = {}
 
@@ -69,6 +81,57 @@ class Runtime:
     def empty(self, shape, dtype):
         torch = _torch()
         return torch.empty(shape, dtype=dtype, device=self.torch_device)
+
+    # ---- copies beside the compute stream ----------------------------------
+    def copy_stream(self):
+        """A second stream for host-to-device copies that must not queue behind (or stall)
+        the kernels of the compute stream; consumers wait for the copy's event."""
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = _torch().cuda.Stream(device=self.torch_device)
+        return self._copy_stream
+
+    def copy_into_async(self, dst, pinned_src):
+        """``dst.copy_(pinned_src)`` on the copy stream; returns the event that marks its end.
+        ``dst`` must not be in use by kernels already enqueued (the caller owns it)."""
+        torch = _torch()
+        with torch.cuda.device(self.device), torch.cuda.stream(self.copy_stream()):
+            dst.copy_(pinned_src, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        return ev
+
+    def upload_cached(self, a, dtype):
+        """Device copy of a host vector (labels, propensities), remembered for the next
+        ``fit()`` on the same array object with the same contents (cheap sample check, as
+        ``CsrCache``): the drivers fit several models on one split."""
+        if not isinstance(a, np.ndarray) or a.size == 0 or not self.remember_splits:
+            return self.upload(np.asarray(a), dtype=dtype)
+        cache = self.__dict__.setdefault("_vec_cache", [])
+        key = (id(a), a.shape, a.dtype.str, np.dtype(dtype).str, _sample_hash(a.reshape(-1)))
+        for ref, k, dev in cache:
+            if k == key and ref() is a:
+                return dev
+        dev = self.upload(a, dtype=dtype)
+        try:
+            cache.append((weakref.ref(a), key, dev))
+        except TypeError:
+            return dev
+        if len(cache) > 8:
+            cache.pop(0)
+        return dev
+
+    def log_cache(self) -> "CsrCache":
+        """Device copies of the last few training / validation matrices, shared by the models of
+        this device (the drivers fit FM and MF, IPS and Naive, on one split)."""
+        if getattr(self, "_log_cache", None) is None:
+            self._log_cache = CsrCache(self, capacity=4)
+        return self._log_cache
+
+    def clear_caches(self) -> None:
+        """Forget every remembered upload (logs, label vectors, sampled ids)."""
+        self._log_cache = None
+        self.__dict__.pop("_vec_cache", None)
+        ID_CACHE.clear()
 
     def sync(self) -> None:
         _lib.check(self.lib.rfm_sync(self.ctx))
@@ -139,8 +202,7 @@ class CsrCache:
         for arr in (getattr(X, "data", None), getattr(X, "indices", None), getattr(X, "indptr", None)):
             if arr is None or not len(arr):
                 continue
-            step = max(1, len(arr) // 1024)
-            parts.append(hash(np.concatenate([arr[:64], arr[::step], arr[-64:]]).tobytes()))
+            parts.append(_sample_hash(arr))
         return tuple(parts)
 
     def get(self, X) -> DeviceCSR:
@@ -160,12 +222,14 @@ class CsrCache:
 
 # ---- host-only helpers (no GPU needed) -------------------------------------
 def sample_batches(n_rows: int, batch_size: int, epoch_begin: int, n_epochs: int,
-                   n_threads: int = 0) -> np.ndarray:
+                   n_threads: int = 0, out: Optional[np.ndarray] = None) -> np.ndarray:
     """Row ids of iterations ``epoch_begin .. +n_epochs`` as ``(n_epochs, B)``
     int32 -- what ``resample(..., random_state=epoch)`` selects
     (src/fm.py:72-79).  Raises ValueError if ``batch_size > n_rows``."""
     lib = _lib.load()
-    out = np.empty((max(n_epochs, 0), batch_size), dtype=np.int32)
+    if out is None:
+        out = np.empty((max(n_epochs, 0), batch_size), dtype=np.int32)
+    assert out.shape == (max(n_epochs, 0), batch_size) and out.dtype == np.int32 and out.flags.c_contiguous
     if n_threads <= 0:
         n_threads = min(os.cpu_count() or 1, 32)
     _lib.check(lib.rfm_sample_batches(n_rows, batch_size, epoch_begin, n_epochs,
@@ -187,11 +251,32 @@ class _IdCache:
         self._lock = threading.Lock()
         self._rows: Dict[Tuple[int, int], np.ndarray] = {}
         self._bytes = 0
+        self._dev: Dict[Tuple[int, int, int], object] = {}
 
     def clear(self) -> None:
         with self._lock:
             self._rows.clear()
             self._bytes = 0
+            self._dev.clear()
+
+    # whole fits' ids resident in HBM: (device, n_rows, batch_size) -> int32 tensor [epochs][B]
+    DEV_CAP_BYTES = 1 << 30
+
+    def get_device(self, device: int, n_rows: int, batch_size: int, n_epochs: int):
+        with self._lock:
+            t = self._dev.get((device, n_rows, batch_size))
+        return t if t is not None and t.shape[0] >= n_epochs else None
+
+    def put_device(self, device: int, n_rows: int, batch_size: int, ids) -> None:
+        with self._lock:
+            key = (device, n_rows, batch_size)
+            old = self._dev.get(key)
+            if old is not None and old.shape[0] >= ids.shape[0]:
+                return
+            self._dev[key] = ids
+            total = lambda: sum(t.numel() * 4 for t in self._dev.values())  # noqa: E731
+            while total() > self.DEV_CAP_BYTES and len(self._dev) > 1:
+                self._dev.pop(next(k for k in self._dev if k != key))
 
     def get(self, n_rows: int, batch_size: int, first: int, count: int) -> Optional[np.ndarray]:
         with self._lock:
@@ -222,14 +307,21 @@ class BatchIdStream:
     cores -- one iteration per thread -- and is overlapped rather than moved).  The first,
     small chunk is sampled in the constructor (a batch larger than the log raises there,
     before anything is uploaded); a background thread samples the rest, exact ``resample``
-    ids, while the caller uploads the log, builds the plan and the GPU trains."""
+    ids, while the caller uploads the log, builds the plan and the GPU trains.
+
+    ``need_host=False`` (FM: nothing on the host reads the ids): the fit's ids live in ONE
+    device buffer; every chunk is sampled straight into pinned memory and copied on the
+    runtime's copy stream by the sampler thread, and the consumer only makes the compute stream
+    wait for the copy's event -- no upload blocks the host or queues behind the kernels.  The
+    filled buffer is remembered (``ID_CACHE``): another fit on a log of the same length with
+    the same batch size samples and uploads nothing."""
 
     CHUNK_IDS = 1 << 23   # most ids per chunk: 32 MiB of int32
     FIRST_ITERS = 16      # iterations of the first chunk: the GPU starts after one sampler round
     CHUNK_ITERS = 64      # iterations of the later chunks
     QUEUE_DEPTH = 4       # sampled chunks waiting for the consumer
 
-    def __init__(self, rt: Runtime, n_rows: int, batch_size: int, n_epochs: int):
+    def __init__(self, rt: Runtime, n_rows: int, batch_size: int, n_epochs: int, need_host: bool = True):
         import queue
         import threading
 
@@ -241,42 +333,95 @@ class BatchIdStream:
             cuts.append((at, size))
             at += size
         self._cuts = cuts
-        self._first = self._sample(*cuts[0]) if cuts else None
         self._queue: "queue.Queue" = queue.Queue(maxsize=self.QUEUE_DEPTH)
         self._stop = False
         self._thread = None
+        self._dev_all = None     # the fit's ids in HBM (need_host=False)
+        self._resident = False   # ... found there: nothing to sample
+        self._staging = []       # [pinned buffer, event of the copy that last read it]
+        self._first = None
+        if not cuts:
+            return
+        if batch_size > n_rows:
+            sample_batches(n_rows, batch_size, 0, 1)  # raises the sampler's ValueError
+        total = n_epochs * batch_size * 4
+        if not need_host and total <= ID_CACHE.DEV_CAP_BYTES:
+            got = ID_CACHE.get_device(rt.device, n_rows, batch_size, n_epochs)
+            if got is not None:
+                self._dev_all, self._resident = got, True
+                return
+            torch = _torch()
+            self._dev_all = rt.empty((n_epochs, batch_size), torch.int32)
+            with torch.cuda.device(rt.device):  # (the block may have had a user on the compute stream)
+                rt.copy_stream().wait_stream(torch.cuda.current_stream())
+            rows = max(size for _, size in cuts)
+            self._staging = [[torch.empty((rows, batch_size), dtype=torch.int32, pin_memory=True), None]
+                             for _ in range(2)]
+            self._first = self._produce(0, *cuts[0])
+        else:
+            self._first = self._sample(*cuts[0])
         if len(cuts) > 1:
             self._thread = threading.Thread(target=self._work, name="rfm-sampler", daemon=True)
             self._thread.start()
 
-    def _sample(self, first: int, count: int) -> np.ndarray:
+    def _sample(self, first: int, count: int, out: Optional[np.ndarray] = None) -> np.ndarray:
         got = ID_CACHE.get(self.n_rows, self.batch_size, first, count)
         if got is None:
-            got = sample_batches(self.n_rows, self.batch_size, first, count)
+            got = sample_batches(self.n_rows, self.batch_size, first, count, out=out)
             ID_CACHE.put(self.n_rows, first, got)
+        elif out is not None:
+            out[...] = got
+            got = out
         return got
+
+    def _produce(self, index: int, first: int, count: int):
+        """Chunk ``index`` into its slice of the device buffer; returns the copy's event."""
+        slot = self._staging[index % 2]
+        if slot[1] is not None:
+            slot[1].synchronize()  # the copy that read this pinned buffer two chunks ago
+        pinned = slot[0][:count]
+        self._sample(first, count, out=pinned.numpy())
+        slot[1] = self.rt.copy_into_async(self._dev_all[first:first + count], pinned)
+        return slot[1]
 
     def _work(self) -> None:
         try:
-            for first, count in self._cuts[1:]:
+            for index, (first, count) in enumerate(self._cuts[1:], start=1):
                 if self._stop:
                     return
-                self._queue.put((first, self._sample(first, count)))
+                if self._dev_all is not None:
+                    self._queue.put((first, self._produce(index, first, count)))
+                else:
+                    self._queue.put((first, self._sample(first, count)))
         except BaseException as exc:  # noqa: BLE001 -- handed to the consumer
             self._queue.put((None, exc))
 
     def chunks(self):
-        """Yields ``(first_epoch, host_ids (count, B), device_ids)`` in order."""
+        """Yields ``(first_epoch, host_ids (count, B) or None, device_ids (count, B))`` in
+        order; the device ids are valid for work enqueued on the compute stream after the
+        yield."""
+        if self._resident:
+            if self._cuts:
+                yield 0, None, self._dev_all[: self.n_epochs]
+            return
+        torch = _torch()
+        complete = False
         try:
-            for i, (first, _) in enumerate(self._cuts):
+            for i, (first, count) in enumerate(self._cuts):
                 if i == 0:
-                    host = self._first
+                    got = self._first
                 else:
-                    got_first, host = self._queue.get()
+                    got_first, got = self._queue.get()
                     if got_first is None:
-                        raise host
+                        raise got
                     assert got_first == first
-                yield first, host, self.rt.upload(host)
+                if self._dev_all is not None:
+                    with torch.cuda.device(self.rt.device):
+                        torch.cuda.current_stream().wait_event(got)  # GPU-side: the host goes on
+                    yield first, None, self._dev_all[first:first + count]
+                else:
+                    yield first, got, self.rt.upload(got)
+            complete = True
         finally:
             self._stop = True
             if self._thread is not None:
@@ -285,6 +430,12 @@ class BatchIdStream:
                         self._queue.get_nowait()
                     except Exception:  # noqa: BLE001 -- empty
                         self._thread.join(timeout=0.01)
+            if self._dev_all is not None:
+                for _, ev in self._staging:
+                    if ev is not None:
+                        ev.synchronize()
+                if complete:
+                    ID_CACHE.put_device(self.rt.device, self.n_rows, self.batch_size, self._dev_all)
 
 
 def mf_schedule(users: np.ndarray, items: np.ndarray, n_users: int, n_items: int):

@@ -90,6 +90,7 @@ def test_fit_with_ids_sampled_in_chunks(rfm):
     chunk before): three iterations per chunk here, same result as the reference's fit."""
     pkg, _lib, runtime, rt = rfm
     old = runtime.BatchIdStream.CHUNK_IDS
+    rt.clear_caches()  # (ids resident from an earlier fit would bypass the chunks)
     try:
         for fixture, shape, cls in (("fm_coat_k8", "coat", "FM"), ("mf_small", "kuairec_small", "MF")):
             g = load_golden(fixture)
@@ -114,6 +115,48 @@ def test_fit_with_ids_sampled_in_chunks(rfm):
             assert rel_err(tr, g["IPS_train_loss"]) < TIGHT and rel_err(va, g["IPS_val_loss"]) < TIGHT
     finally:
         runtime.BatchIdStream.CHUNK_IDS = old
+
+
+def test_fit_remembers_the_split_and_notices_edits(rfm):
+    """A second fit on the same split reuses the device copies of the log, the labels and the
+    row ids (nothing sampled or uploaded) and gives the same result; labels edited in place
+    are uploaded again; `remember_splits = False` uploads every time.  All against the oracle."""
+    pkg, _lib, runtime, rt = rfm
+    rng = np.random.default_rng(99)
+    train = _random_log(rng, 3000, 70, 0.1, 1)
+    val = _random_log(rng, 200, 70, 0.1, 1)
+    kw = dict(n_factors=6, n_features=70, lr=1e-3, batch_size=512, n_epochs=40, seed=3)
+    rt.clear_caches()
+
+    def check(model, tr, va, data):
+        ref = cpu_ref.fm_fit(data, val, n_epochs=40, n_factors=6, lr=1e-3, batch_size=512, seed=3)
+        assert rel_err(model.V(), ref["V"]) < TIGHT and rel_err(model.w(), ref["w"]) < TIGHT
+        assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
+
+    m1 = _fm(pkg, **kw)
+    check(m1, *m1.fit(train, val), train)
+    assert runtime.ID_CACHE.get_device(rt.device, 3000, 512, 40) is not None
+    dev_log = rt.log_cache().get(train["features"])
+    m2 = _fm(pkg, **kw)
+    check(m2, *m2.fit(train, val), train)
+    assert rt.log_cache().get(train["features"]) is dev_log  # the same device copy served both
+    assert rel_err(m1.V(), m2.V()) < 1e-12  # (hot-column sums are LDS atomics: last bits may differ)
+    # labels flipped in place (same array object): the stale device copy must not be used
+    train["labels"][:] = 1 - train["labels"]
+    m3 = _fm(pkg, **kw)
+    check(m3, *m3.fit(train, val), train)
+    # features scaled in place
+    train["features"].data *= 0.5
+    m4 = _fm(pkg, **kw)
+    check(m4, *m4.fit(train, val), train)
+    # and with the caches switched off
+    old = runtime.Runtime.remember_splits
+    try:
+        runtime.Runtime.remember_splits = False
+        m5 = _fm(pkg, **kw)
+        check(m5, *m5.fit(train, val), train)
+    finally:
+        runtime.Runtime.remember_splits = old
 
 
 def test_dcg_parity_on_gpu_scores(rfm):

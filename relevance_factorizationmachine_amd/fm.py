@@ -11,6 +11,7 @@ loop runs in the kernels of ``csrc/rfm_fm.hip``.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 from typing import Optional
 
@@ -21,6 +22,57 @@ from .base import LOSS_EPS, PointwiseBaseRecommender
 from .evaluate import EvalLoop, device_frame
 from .optimizer import DeviceSGD
 from .runtime import BatchIdStream, CsrCache, DeviceCSR, Runtime
+
+
+class _PlanCache:
+    """The last few training plans of a device, by the identity of the device copies they were
+    built from (log, labels, propensities) and their shape parameters: a second model fitted on
+    the same split with the same factor count and batch size takes the plan as it is (a plan
+    holds no model state).  A plan that is lent out is not lent twice."""
+
+    CAPACITY = 2
+
+    def __init__(self):
+        self._items = []  # [key, (weakrefs), plan, busy]
+
+    def take(self, rt, csr, y, p, n_factors: int, max_batch: int, hot_min_count: int) -> "FmPlan":
+        key = (id(csr), id(y), id(p), n_factors, max_batch, hot_min_count)
+        for item in self._items:
+            if item[0] == key and not item[3] and all(r() is o for r, o in zip(item[1], (csr, y, p))):
+                item[3] = True
+                return item[2]
+        plan = FmPlan(rt, csr, y, p, n_factors, max_batch, hot_min_count)
+        try:
+            refs = tuple(weakref.ref(o) for o in (csr, y, p))
+        except TypeError:
+            return plan  # not remembered: give_back() closes it
+        self._items.append([key, refs, plan, True])
+        while len(self._items) > self.CAPACITY:
+            for i, item in enumerate(self._items):
+                if not item[3]:
+                    self._items.pop(i)[2].close()
+                    break
+            else:
+                break
+        return plan
+
+    def give_back(self, plan: "FmPlan") -> None:
+        for item in self._items:
+            if item[2] is plan:
+                item[3] = False
+                return
+        plan.close()
+
+    def clear(self) -> None:
+        for item in [i for i in self._items if not i[3]]:
+            self._items.remove(item)
+            item[2].close()
+
+
+def plan_cache(rt: Runtime) -> _PlanCache:
+    if getattr(rt, "_plan_cache", None) is None:
+        rt._plan_cache = _PlanCache()
+    return rt._plan_cache
 
 
 class FmPlan:
@@ -142,8 +194,9 @@ class FactorizationMachines(PointwiseBaseRecommender):
               (rt.log_cache().get(val["features"]) if keep else DeviceCSR(rt, val["features"])))
         vy = rt.upload_cached(val["labels"], np.float64)
         vp = rt.upload_cached(val["pscores"], np.float64)
-        plan = FmPlan(rt, tr, y, p, self.n_factors, self.batch_size,
-                      -1 if self.deterministic else self.hot_min_count)
+        hot = -1 if self.deterministic else self.hot_min_count
+        plan = (plan_cache(rt).take(rt, tr, y, p, self.n_factors, self.batch_size, hot) if keep
+                else FmPlan(rt, tr, y, p, self.n_factors, self.batch_size, hot))
         self.plan_info = dict(plan.info(), **plan.layout())  # (what the last fit trained with)
         tl = rt.empty((self.n_epochs,), y.dtype)
         vl = rt.empty((self.n_epochs,), y.dtype)
@@ -207,7 +260,10 @@ class FactorizationMachines(PointwiseBaseRecommender):
             rt.sync()
         finally:
             rt.sync()
-            plan.close()
+            if keep:
+                plan_cache(rt).give_back(plan)
+            else:
+                plan.close()
         return tl.cpu().numpy().tolist(), vl.cpu().numpy().tolist()
 
     # -------------------------------------------------------------- predict

@@ -131,6 +131,8 @@ class Runtime:
         """Forget every remembered upload (logs, label vectors, sampled ids)."""
         self._log_cache = None
         self.__dict__.pop("_vec_cache", None)
+        if getattr(self, "_plan_cache", None) is not None:
+            self._plan_cache.clear()
         ID_CACHE.clear()
 
     def sync(self) -> None:

@@ -217,6 +217,7 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   f.rows = plan->rows.as<RowRec>();
   f.ell = plan->ell.as<char>();
   f.ell_stride = plan->ell_stride;
+  f.ell_yp = plan->ell_yp.as<double2>();
   f.row_ids = d_row_ids;
   f.n_rows = batch;
   f.w0 = d_w0;
@@ -636,6 +637,7 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
         f.rows = plan->rows.as<RowRec>();
         f.ell = plan->ell.as<char>();
         f.ell_stride = plan->ell_stride;
+        f.ell_yp = plan->ell_yp.as<double2>();
         f.row_ids = ids;
         f.n_rows = batch;
         f.w0 = d_w0;

@@ -101,6 +101,9 @@ constexpr int kBigBlock = RFM_FWD_BIG_BLOCK;  // threads of the forward's many-r
 #endif
 
 // entries of a row whose V gathers the one-row forward shape keeps in flight
+#ifndef RFM_FWD_BIG_UNROLL
+#define RFM_FWD_BIG_UNROLL 3
+#endif
 #ifndef RFM_FWD_SMALL_UNROLL
 #define RFM_FWD_SMALL_UNROLL 8
 #endif
@@ -116,7 +119,8 @@ struct FwdArgs {
   const Entry* ent;
   const RowRec* rows;
   const char* ell;       // ... in their padded form when every row fits one round: row blocks
-  int64_t ell_stride;    //     {EllHdr, Entry[LPR]} of this many bytes (then ent / rows are null)
+  int64_t ell_stride;    //     Entry[LPR] of this many bytes (then ent / rows are null), with
+  const double2* ell_yp; //     the rows' {label, propensity} pairs (one line per row)
   // ... or the caller's CSR arrays (+ labels / propensities when a loss is asked for)
   const int64_t* indptr;
   const int32_t* indices;
@@ -239,13 +243,19 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
     if (ell) {
 #pragma unroll
       for (int i = 0; i < R; ++i) {
-        const char* blk = a.ell + int64_t(r[i]) * a.ell_stride;
-        const EllHdr hd = *reinterpret_cast<const EllHdr*>(blk);
-        e0[i] = reinterpret_cast<const Entry*>(blk + sizeof(EllHdr))[l];
+        e0[i] = reinterpret_cast<const Entry*>(a.ell + int64_t(r[i]) * a.ell_stride)[l];
+        const double2 yp = a.ell_yp[r[i]];
+        yy[i] = yp.x;
+        pp[i] = yp.y;
         p0[i] = 0;
-        len[i] = valid[i] ? hd.len : 0;
-        yy[i] = hd.y;
-        pp[i] = hd.p;
+      }
+      // the row's length: its entries that are not padding (they come first)
+      constexpr int GPW = kWave / LPR;  // lane groups of a wave
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        unsigned long long live = __ballot(e0[i].slot != kNilSlot);
+        if (GPW > 1) live = (live >> ((g % GPW) * LPR)) & ((1ull << (LPR % 64)) - 1ull);
+        len[i] = valid[i] ? __popcll(live) : 0;
       }
     }
 #pragma unroll
@@ -329,7 +339,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
       const int cnt = (maxlen - pb) < LPR ? (maxlen - pb) : LPR;
       // entries whose gathers are in flight together: the many-rows shape is at its register
       // budget with two (x R rows); the one-row shape has registers to spare
-#pragma unroll(BLOCK == kBigBlock || NC > 1 ? 2 : RFM_FWD_SMALL_UNROLL)
+#pragma unroll(BLOCK == kBigBlock || NC > 1 ? (NC == 1 && (ELL || !REC) ? RFM_FWD_BIG_UNROLL : 2) : RFM_FWD_SMALL_UNROLL)
       for (int j = 0; j < cnt; ++j) {
         Entry ej[R];
         Pack<VEC> pv[R][NC];
@@ -408,9 +418,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
     int32_t touched[R];
     if (warm) {
 #pragma unroll
-      for (int i = 0; i < R; ++i)  // lane l touches the 16 bytes of its own entry; lane 0's line holds the head
+      for (int i = 0; i < R; ++i)  // lane l touches the 16 bytes of its own entry
         touched[i] = *reinterpret_cast<const int32_t*>(a.ell + int64_t(nxt[i]) * a.ell_stride +
-                                                      (l == 0 ? 0 : int(sizeof(EllHdr)) + 16 * l));
+                                                      16 * l);
     }
     if (REC && (a.slot_mark || (H > 0 && RFM_KEEP(a, 32)))) {
       // after the residual is known: marks of the sparse-class entries, and the hot

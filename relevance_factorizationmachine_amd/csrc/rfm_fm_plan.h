@@ -17,6 +17,7 @@ struct rfm_fm_plan {
   int64_t step = 0;  // stamps the partial rows of a step
   int32_t fwd_grid_max = 0;  // forward workgroups of a max_batch step (= hot-sum slabs)
   rfm::DevBuf ell;            // padded row blocks (every row <= lanes-per-group entries), else empty
+  rfm::DevBuf ell_yp;         // ... with the rows' {label, propensity} pairs
   int64_t ell_stride = 0;
   rfm::DevBuf ent, rows, slot_t, slot_bits, slots, tasks, split, parts, Q, err, hot_cols, hot_slab,
       err_partial;
@@ -30,7 +31,7 @@ struct rfm_fm_plan {
   rfm::DevBuf ids_seen, ids_flags;  // RFM_CHECK_IDS=1: validation of the steps' row ids
   int32_t ids_stamp = 0;
   size_t device_bytes() const {
-    return ell.bytes + ent.bytes + rows.bytes + slot_t.bytes + slot_bits.bytes + slots.bytes + tasks.bytes +
+    return ell.bytes + ell_yp.bytes + ent.bytes + rows.bytes + slot_t.bytes + slot_bits.bytes + slots.bytes + tasks.bytes +
            split.bytes + parts.bytes + Q.bytes + err.bytes + hot_cols.bytes + hot_slab.bytes +
            err_partial.bytes;
   }

@@ -93,27 +93,25 @@ __global__ __launch_bounds__(kBlock) void plan_scatter_kernel(const int32_t* key
   }
 }
 
-// padded row blocks {EllHdr, Entry[lpr]}: the entries past the row's end repeat its last entry
-// with x = 0 and no slot (what the forward pads a short round with)
+// padded row blocks Entry[lpr] (rfm_fm_records.h) + the rows' {label, propensity} pairs
 __global__ __launch_bounds__(kBlock) void plan_ell_kernel(const RowRec* rows, const Entry* ent,
                                                          int64_t n_rows, int lpr, char* ell,
-                                                         int64_t stride) {
+                                                         int64_t stride, double2* ell_yp) {
   for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n_rows * lpr;
        i += int64_t(gridDim.x) * kBlock) {
     const int64_t r = i / lpr;
     const int j = int(i % lpr);
     const RowRec rec = rows[r];
-    char* blk = ell + r * stride;
-    if (j == 0) *reinterpret_cast<EllHdr*>(blk) = EllHdr{int32_t(rec.len), 0, rec.y, rec.p, 0.0};
-    Entry e{0, 0, 0.0};
+    if (j == 0) ell_yp[r] = make_double2(rec.y, rec.p);
+    Entry e{0, kNilSlot, 0.0};
     if (rec.len > 0) {
       e = ent[rec.begin + (j < rec.len ? j : rec.len - 1)];
       if (j >= rec.len) {
-        e.slot = 0;
+        e.slot = kNilSlot;
         e.x = 0.0;
       }
     }
-    reinterpret_cast<Entry*>(blk + sizeof(EllHdr))[j] = e;
+    reinterpret_cast<Entry*>(ell + r * stride)[j] = e;
   }
 }
 
@@ -341,11 +339,12 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
   plan->max_row_len = int32_t(max_len);
   if (nnz > 0 && max_len <= shp.lpr && forward_many_rows(ctx, max_batch, n_factors) &&
       env_int("RFM_NO_ELL", 0) == 0) {
-    plan->ell_stride = int64_t(sizeof(EllHdr)) + int64_t(shp.lpr) * int64_t(sizeof(Entry));
+    plan->ell_stride = int64_t(shp.lpr) * int64_t(sizeof(Entry));
     plan->ell.alloc(nr * size_t(plan->ell_stride));
+    plan->ell_yp.alloc(nr * 16);
     hipLaunchKernelGGL(plan_ell_kernel, dim3(grid_for(ctx, n_rows * shp.lpr)), dim3(kBlock), 0, st,
                        plan->rows.as<RowRec>(), plan->ent.as<Entry>(), n_rows, shp.lpr,
-                       plan->ell.as<char>(), plan->ell_stride);
+                       plan->ell.as<char>(), plan->ell_stride, plan->ell_yp.as<double2>());
     RFM_HIP_CHECK(hipGetLastError());
     RFM_HIP_CHECK(hipStreamSynchronize(st));
     plan->ent.release();

@@ -19,13 +19,12 @@ struct RowRec {      // one row of the training log, 32 B
   double y;          // label
   double p;          // propensity (already raised to pow_used by the loader)
 };
-struct EllHdr {      // head of a row block of the padded form of the log (rows of <= LPR entries):
-  int32_t len;       // {EllHdr, Entry[LPR]} at a fixed stride, so that the row's record AND its
-  int32_t pad;       // entries are one dependent load behind the row id, not two; 32 B
-  double y;
-  double p;
-  double pad2;
-};
+// The padded form of the log (plans whose longest row fits one round of a lane group): row
+// blocks Entry[LPR] at a fixed stride (256 B at k = 32: two whole cache lines), so that a row's
+// entries are ONE dependent load behind the row id (not row record -> entries).  The entries
+// past the row's end repeat its last entry with x = 0 and slot kNilSlot: the row's length is
+// the count of the others.  {label, propensity} pairs sit in a plain array by row.
+constexpr int32_t kNilSlot = INT32_MIN;
 struct SlotRec {  // one slot of the column-major view, 16 B
   double x;       // feature value
   int32_t col;    // feature column

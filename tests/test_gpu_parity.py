@@ -331,7 +331,7 @@ def test_fm_fit_padded_row_blocks(rfm, k, max_len, n_rows, hot):
     model.hot_min_count = hot
     tr, va = model.fit(train, val)
     assert model.plan_info["row_blocks"] == 1 and model.plan_info["longest_row"] == max_len
-    assert model.plan_info["row_block_bytes"] == 32 + 16 * model.plan_info["lanes_per_row"]
+    assert model.plan_info["row_block_bytes"] == 16 * model.plan_info["lanes_per_row"]
     ref = cpu_ref.fm_fit(train, val, n_epochs=2, n_factors=k, lr=lr, batch_size=batch, seed=5)
     assert rel_err(model.V(), ref["V"]) < TIGHT
     assert rel_err(model.w(), ref["w"]) < TIGHT

@@ -624,6 +624,16 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
                            val_rows, int64_t(kMaxFwdGrid), val_parts, n_val, d_out_val_loss + first);
       RFM_HIP_CHECK(hipGetLastError());
     };
+    // RFM_TRAIN_GRAPH=1 (timing experiment): the run's launches captured into one hipGraph on
+    // a stream of its own (the legacy default stream cannot be captured) and replayed once
+    static const bool as_graph = env_int("RFM_TRAIN_GRAPH", 0) != 0;
+    hipStream_t user_stream = ctx->stream, cap_stream = nullptr;
+    if (as_graph && !ctx->profiling) {
+      RFM_HIP_CHECK(hipStreamSynchronize(user_stream));
+      RFM_HIP_CHECK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+      ctx->stream = cap_stream;
+      RFM_HIP_CHECK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+    }
     int64_t run_first = 0;
     for (int64_t it = 0; it < n_iters; ++it) {
       const int32_t* ids = d_ids + it * batch;
@@ -661,6 +671,25 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
       }
     }
     finish(run_first, n_iters - run_first);
+    if (cap_stream) {
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      ctx->stream = user_stream;
+      RFM_HIP_CHECK(hipStreamEndCapture(cap_stream, &graph));
+      RFM_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      static const bool timed = env_int("RFM_TRAIN_GRAPH", 0) > 1;
+      const auto t0 = std::chrono::steady_clock::now();
+      RFM_HIP_CHECK(hipGraphLaunch(exec, cap_stream));
+      RFM_HIP_CHECK(hipStreamSynchronize(cap_stream));
+      if (timed)
+        fprintf(stderr, "[rfm] graph of %lld iterations: %.2f us per iteration (launch to drain)\n",
+                (long long)n_iters,
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() /
+                    double(n_iters));
+      (void)hipGraphExecDestroy(exec);
+      (void)hipGraphDestroy(graph);
+      (void)hipStreamDestroy(cap_stream);
+    }
   });
 }
 

@@ -205,6 +205,70 @@ def test_grad_rows_is_the_dense_gradient_on_the_touched_columns():
     plan.close()
 
 
+def test_gradient_entry_points_at_a_many_rows_batch():
+    """The gradient forms of the step at a batch that takes the forward's many-rows shape over
+    padded row blocks (40 000 rows of the KuaiRec-big-shaped log, k = 32): the dense
+    gradient against the oracle's closed form, the touched-row records against the dense
+    gradient, and records applied = the fused step."""
+    import torch
+    import relevance_factorizationmachine_amd as pkg
+    from oracle import cpu_ref
+    from relevance_factorizationmachine_amd import _lib
+    from relevance_factorizationmachine_amd.fm import FmPlan
+    from relevance_factorizationmachine_amd.runtime import DeviceCSR, Runtime, sample_batches
+
+    batch, k, lr = 40_000, 32, 9e-6
+    train, _ = synth.make_log("kuairec_big", "FM", "IPS", seed=0, n_train=100_000, n_val=16)
+    X = train["features"]
+    n = X.shape[1]
+    rt = Runtime.get(0)
+    kw = dict(estimator="IPS", n_epochs=1, n_factors=k, lr=lr, batch_size=batch, seed=12345, n_features=n)
+    model, ref = pkg.FactorizationMachines(**kw), pkg.FactorizationMachines(**kw)
+    csr = DeviceCSR(rt, X)
+    y = rt.upload(train["labels"], dtype=np.float64)
+    p = rt.upload(train["pscores"], dtype=np.float64)
+    plan = FmPlan(rt, csr, y, p, k, batch)
+    assert plan.layout()["row_blocks"] == 1
+    host_ids = sample_batches(X.shape[0], batch, 0, 2)
+    ids = rt.upload(host_ids)
+    csr_ptrs = (csr.indptr.data_ptr(), csr.indices.data_ptr(), csr.values.data_ptr(), y.data_ptr(), p.data_ptr())
+
+    # dense gradient vs the oracle
+    dense = rt.empty((n * (k + 1) + 1,), torch.float64)
+    _lib.check(rt.lib.rfm_fm_grad(rt.ctx, plan.handle, *csr_ptrs, ids.data_ptr(), batch,
+                                  model.w0.dev.data_ptr(), model.w.dev.data_ptr(), model.V.dev.data_ptr(),
+                                  dense.data_ptr()))
+    rt.sync()
+    g = dense.cpu().numpy()
+    GV, gw, gw0 = g[: n * k].reshape(n, k), g[n * k: n * k + n], g[-1]
+    rows0 = host_ids[0]
+    _, o_w0, o_w, o_V = cpu_ref.fm_gradients(X[rows0], train["labels"][rows0].astype(np.float64),
+                                             train["pscores"][rows0], model.w0(), model.w(), model.V())
+    assert rel_err(GV, o_V) < 1e-11 and rel_err(gw, o_w) < 1e-11 and abs(gw0 - o_w0) < 1e-9 * max(1.0, abs(o_w0))
+    # touched-row records = the dense gradient on the touched columns
+    rows, n_rows, r_w0, _ = _grad_rows(rt, plan, model, ids.data_ptr(), batch, n)
+    cnt = int(n_rows.cpu()[0])
+    rec = rows.cpu().numpy()[:cnt]
+    cols = rec[:, 0].astype(np.int64)
+    np.testing.assert_array_equal(cols, np.union1d(np.unique(X[rows0].indices), plan.hot_columns()))
+    assert rel_err(rec[:, 1:-1], GV[cols]) < 1e-12 and rel_err(rec[:, -1], gw[cols]) < 1e-12
+    assert rel_err(r_w0.cpu().numpy(), g[-1:]) < 1e-12
+    # records applied = the fused step, two iterations
+    plan2 = FmPlan(rt, csr, y, p, k, batch)
+    for it in range(2):
+        rows, n_rows, r_w0, _ = _grad_rows(rt, plan, model, ids.data_ptr() + it * batch * 4, batch, n)
+        _lib.check(rt.lib.rfm_fm_apply_rows(rt.ctx, rows.data_ptr(), n_rows.data_ptr(), n, r_w0.data_ptr(),
+                                            model.w0.dev.data_ptr(), model.w.dev.data_ptr(),
+                                            model.V.dev.data_ptr(), n, k, lr))
+        _lib.check(rt.lib.rfm_fm_step(rt.ctx, plan2.handle, *csr_ptrs, ids.data_ptr() + it * batch * 4, batch,
+                                      ref.w0.dev.data_ptr(), ref.w.dev.data_ptr(), ref.V.dev.data_ptr(), lr))
+    rt.sync()
+    assert rel_err(model.V(), ref.V()) < 1e-12 and rel_err(model.w(), ref.w()) < 1e-12
+    assert rel_err(model.w0(), ref.w0()) < 1e-12
+    plan.close()
+    plan2.close()
+
+
 def test_grad_rows_then_apply_rows_equals_step():
     from relevance_factorizationmachine_amd import _lib
 

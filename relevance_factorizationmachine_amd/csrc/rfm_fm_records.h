@@ -43,7 +43,10 @@ struct TaskRec {      // one task of fm_consume_kernel: task_words x 64 consecut
   int32_t part;       // >= 0: the task starts a workgroup that lies inside a column longer than a
                       // workgroup's tasks; the workgroup's sums go to this partial row
 };
-constexpr int kTaskTrips = 1;  // bitmap words of its task a lane loads (task_words <= lanes of a group)
+#ifndef RFM_TASK_TRIPS
+#define RFM_TASK_TRIPS 1
+#endif
+constexpr int kTaskTrips = RFM_TASK_TRIPS;  // bitmap words of its task a lane loads (task_words <= lanes of a group)
 struct SplitCol {      // a sparse-class column longer than a whole workgroup's tasks
   int32_t col;
   int32_t part_begin;  // its partial rows: parts[part_begin .. +part_count), in slot order

@@ -130,8 +130,14 @@ int32_t rfm_fm_forward_loss(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t
  * hot_min_count: a column
  * whose expected number of entries per batch (its training frequency *
  * max_batch / n_rows) reaches this value is accumulated on chip by the forward
- * workgroups instead of through its column list (0 = library default,
- * <0 = never: every sum then has a fixed order). */
+ * workgroups instead of through its column list (0 = library default).  The on-chip
+ * sums of the default form are LDS float atomics: their last bits depend on arrival
+ * order.  -1 = no such columns: every sum of a step has a fixed order (bitwise
+ * reproducible results).  -2 = the default columns, summed in a fixed order as well
+ * (each column's rows of a forward workgroup in row order, the workgroups in block
+ * order): bitwise reproducible at a fraction of -1's cost; where the factor count has
+ * no such kernel (more than 128 factors, or fewer than 17 at batches of the many-rows
+ * shape) it means -1. */
 int32_t rfm_fm_plan_create(rfm_ctx* ctx, const int64_t* h_indptr, const int32_t* h_indices,
                            const double* h_values, const double* h_y, const double* h_pscore,
                            int64_t n_rows, int64_t n_features, int32_t n_factors,

@@ -77,53 +77,63 @@ bool forward_many_rows(const rfm_ctx* ctx, int64_t rows, int n_factors) {
   return forward_geom(ctx, rows, shape_for(n_factors), true).block == kBigBlock;
 }
 
-inline size_t forward_lds_bytes(int block, int lpr, int rows, int n_hot, int k) {
-  return size_t(block) * 8 + (size_t(block) * rows + size_t(block / lpr)) * sizeof(Entry) +
-         size_t(n_hot) * size_t(k + 2) * 8;
+// one instantiation: raises its dynamic-LDS limit when a launch needs more than the default
+template <int L, int Vv, int N, int BLOCK, int R, bool REC, bool ELL, bool DET>
+void launch_forward_as(rfm_ctx* ctx, const FwdArgs& a, const FwdGeom& geom, size_t lds) {
+  const auto kern = &fm_forward_kernel<L, Vv, N, BLOCK, R, REC, ELL, DET>;
+  static size_t lds_allowed = 64u << 10;
+  if (lds > lds_allowed) {
+    RFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    lds_allowed = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(geom.grid), dim3(BLOCK), lds, ctx->stream, a);
+}
+
+// the instantiation a launch takes: shape of the workgroups (geom), source of the records,
+// and -- for a plan that asks for them -- fixed-order hot sums
+template <int L, int Vv, int N>
+void launch_forward_shape(rfm_ctx* ctx, const FwdArgs& a, const FwdGeom& geom, size_t lds,
+                          bool recs, bool fixed) {
+  constexpr int R = rows_in_flight(N);
+  if (geom.block == kBigBlock) {
+    if (!recs) return launch_forward_as<L, Vv, N, kBigBlock, R, false, false, false>(ctx, a, geom, lds);
+    if constexpr (hot_fixed_order(L, N, kBigBlock, R)) {
+      if (fixed) {
+        if (a.ell) return launch_forward_as<L, Vv, N, kBigBlock, R, true, true, true>(ctx, a, geom, lds);
+        return launch_forward_as<L, Vv, N, kBigBlock, R, true, false, true>(ctx, a, geom, lds);
+      }
+    }
+    RFM_REQUIRE(!fixed, "fixed-order hot sums are not built for this factor count at this batch");
+    if (a.ell) return launch_forward_as<L, Vv, N, kBigBlock, R, true, true, false>(ctx, a, geom, lds);
+    return launch_forward_as<L, Vv, N, kBigBlock, R, true, false, false>(ctx, a, geom, lds);
+  }
+  if (!recs) return launch_forward_as<L, Vv, N, kSmallBlock, 1, false, false, false>(ctx, a, geom, lds);
+  if constexpr (hot_fixed_order(L, N, kSmallBlock, 1)) {
+    if (fixed) return launch_forward_as<L, Vv, N, kSmallBlock, 1, true, false, true>(ctx, a, geom, lds);
+  }
+  RFM_REQUIRE(!fixed, "fixed-order hot sums are not built for this factor count");
+  return launch_forward_as<L, Vv, N, kSmallBlock, 1, true, false, false>(ctx, a, geom, lds);
+}
+
+bool forward_fixed_order_ok(const rfm_ctx* ctx, int64_t max_batch, int n_factors) {
+  const Shape s = shape_for(n_factors);
+  if (!hot_fixed_order(s.lpr, s.nc, kSmallBlock, 1)) return false;  // (steps of fewer rows)
+  return !forward_many_rows(ctx, max_batch, n_factors) ||
+         hot_fixed_order(s.lpr, s.nc, kBigBlock, rows_in_flight(s.nc));
 }
 
 void launch_forward(rfm_ctx* ctx, FwdArgs a, FwdGeom geom) {
   if (a.n_rows <= 0) return;
   const Shape s = shape_for(a.k);
-  const size_t lds =
-      forward_lds_bytes(geom.block, s.lpr, geom.block == kBigBlock ? rows_in_flight(s.nc) : 1, a.n_hot,
-                        a.k);
-
   const bool recs = a.ent != nullptr || a.ell != nullptr;  // the plan's records
-#define RFM_CALL_FWD(L, Vv, N)                                                                \
-  do {                                                                                        \
-    if (recs && geom.block == kBigBlock) {                                                    \
-      static size_t lds_allowed = 64u << 10; /* per instantiation pair: raised on demand */  \
-      if (lds > lds_allowed) {                                                                \
-        RFM_HIP_CHECK(hipFuncSetAttribute(                                                    \
-            reinterpret_cast<const void*>(                                                    \
-                &fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), true, false>),     \
-            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));                           \
-        RFM_HIP_CHECK(hipFuncSetAttribute(                                                    \
-            reinterpret_cast<const void*>(                                                    \
-                &fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), true, true>),      \
-            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));                           \
-        lds_allowed = lds;                                                                    \
-      }                                                                                       \
-      if (a.ell)                                                                              \
-        hipLaunchKernelGGL(                                                                   \
-            (fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), true, true>),          \
-            dim3(geom.grid), dim3(kBigBlock), lds, ctx->stream, a);                           \
-      else                                                                                    \
-        hipLaunchKernelGGL(                                                                   \
-            (fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), true, false>),         \
-            dim3(geom.grid), dim3(kBigBlock), lds, ctx->stream, a);                           \
-    }                                                                                         \
-    else if (geom.block == kBigBlock)                                                         \
-      hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, kBigBlock, rows_in_flight(N), false>),  \
-                         dim3(geom.grid), dim3(kBigBlock), lds, ctx->stream, a);              \
-    else if (recs)                                                                            \
-      hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, kSmallBlock, 1, true>), dim3(geom.grid), \
-                         dim3(kSmallBlock), lds, ctx->stream, a);                             \
-    else                                                                                      \
-      hipLaunchKernelGGL((fm_forward_kernel<L, Vv, N, kSmallBlock, 1, false>), dim3(geom.grid), \
-                         dim3(kSmallBlock), lds, ctx->stream, a);                             \
-  } while (0)
+  const bool fixed = recs && a.hot_fixed && a.n_hot > 0;
+  const size_t lds =
+      forward_lds_bytes(geom.block, s.lpr, s.vec, s.nc,
+                        geom.block == kBigBlock ? rows_in_flight(s.nc) : 1, a.n_hot, a.k, fixed);
+  RFM_REQUIRE(lds <= (160u << 10), "forward kernel: %zu bytes of LDS", lds);
+  RFM_REQUIRE(!fixed || a.hot_rounds >= 1, "hot_rounds unset");
+#define RFM_CALL_FWD(L, Vv, N) launch_forward_shape<L, Vv, N>(ctx, a, geom, lds, recs, fixed)
   RFM_FOR_SHAPE(s, RFM_CALL_FWD);
 #undef RFM_CALL_FWD
   RFM_HIP_CHECK(hipGetLastError());
@@ -229,6 +239,8 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   f.slot_mark = plan->slot_t.as<SlotMark>();
   f.slot_bits = plan->slot_bits.as<unsigned long long>();
   f.n_hot = plan->n_hot;
+  f.hot_rounds = plan->hot_rounds;
+  f.hot_fixed = plan->hot_fixed ? 1 : 0;
   f.hot_slab = plan->hot_slab.as<double>();
   f.err_partial = plan->err_partial.as<double>();
 #ifdef RFM_ABLATE

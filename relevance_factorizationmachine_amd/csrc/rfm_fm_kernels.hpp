@@ -111,6 +111,33 @@ constexpr int kBigBlock = RFM_FWD_BIG_BLOCK;  // threads of the forward's many-r
 // rows a lane group works on concurrently (independent load chains in flight)
 constexpr int rows_in_flight(int nc) { return nc == 1 ? RFM_FWD_ROWS : 1; }
 
+// Hot-class sums in a fixed order (training forward): the rows a workgroup holds in one trip
+// leave their Q rows and per-entry coefficients in LDS, every hot column gets the set of those
+// rows that hold it (a bitmap) and one lane group -- its owner -- adds them up in row order.
+// Possible when a lane holds one chunk of factors and a trip is at most 128 rows; the other
+// shapes add with LDS float atomics (arrival order).
+constexpr bool hot_fixed_order(int lpr, int nc, int block, int rows) {
+  return nc == 1 && (block / lpr) * rows <= 128;
+}
+#ifndef RFM_HOT_U
+#define RFM_HOT_U 2
+#endif
+constexpr int kHotPosPad = 4;  // bytes between the position rows of two columns (bank spread)
+// LDS bytes of the forward kernel (what a launch asks for)
+inline size_t forward_lds_bytes(int block, int lpr, int vec, int nc, int rows, int n_hot, int k,
+                                bool fixed_order) {
+  size_t bytes = size_t(block) * 8 + (size_t(block) * rows + size_t(block / lpr)) * sizeof(Entry) +
+                 size_t(n_hot) * size_t(k + 2) * 8;
+  if (fixed_order && n_hot > 0 && hot_fixed_order(lpr, nc, block, rows)) {
+    const size_t rt = size_t(block / lpr) * rows;
+    bytes += rt * size_t(lpr * vec) * 8;                                 // Q rows of the trip
+    if (rt / 32 > 1) bytes += size_t(block / lpr) * size_t(k + 2) * 8;   // cell sums
+    bytes += ((size_t(n_hot) * ((rt + 31) / 32) + 1) & ~size_t(1)) * 4;  // row sets
+    bytes += (size_t(n_hot) * (rt + kHotPosPad) + 7) / 8 * 8;            // entry positions
+  }
+  return bytes;
+}
+
 // ---------------------------------------------------------------------------
 // 1. forward (+ residual, Q, slot marks, hot sums, loss partials)
 // ---------------------------------------------------------------------------
@@ -139,6 +166,8 @@ struct FwdArgs {
   SlotMark* slot_mark;   // nullable: leave {t, residual} at the slot of every sparse-class entry ...
   unsigned long long* slot_bits;  // ... and set the slot's bit (what fm_consume_kernel scans)
   int32_t n_hot;         // hot columns (training step only)
+  int32_t hot_rounds;    // rounds of LPR entries that cover the longest row of the plan
+  int32_t hot_fixed;     // 1: the plan asks for fixed-order hot sums (the DET instantiations)
   double* hot_slab;      // [n_hot][gridDim.x][k+2]
   double* err_partial;   // nullable: [gridDim.x] per-workgroup sums of the residual (for w0)
   double* loss_partial;  // nullable: [gridDim.x]
@@ -170,7 +199,8 @@ struct FwdArgs {
 // caller's CSR arrays.
 // LDS (dynamic): red[BLOCK] f64 | entry buffer [BLOCK/LPR][R*LPR+1] Entry | hot sums [H][k+2] f64
 // ELL (with REC): the records come as padded row blocks (a.ell).
-template <int LPR, int VEC, int NC, int BLOCK, int R, bool REC, bool ELL = false>
+// DET (with REC): the hot-class sums in a fixed order (hot_fixed_order) instead of LDS atomics.
+template <int LPR, int VEC, int NC, int BLOCK, int R, bool REC, bool ELL = false, bool DET = false>
 __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)) void fm_forward_kernel(
     FwdArgs a) {
   constexpr int GPB = BLOCK / LPR;  // lane groups per block
@@ -186,6 +216,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
   // the broadcast reads of different groups do not collide
   Entry* ebuf = reinterpret_cast<Entry*>(dyn_lds + BLOCK) + g * (R * LPR + 1);
   double* hot = dyn_lds + BLOCK + 2 * (BLOCK * R + GPB);
+  // fixed-order hot sums (see hot_fixed_order): Q rows | row sets | entry positions
+  constexpr bool FIX = DET && REC && hot_fixed_order(LPR, NC, BLOCK, R);
+  constexpr int RT = GPB * R;            // rows of a trip
+  constexpr int KS = LPR * VEC;          // doubles of a parked Q row
+  constexpr int NW = (RT + 31) / 32;     // 32-bit words of a column's row set
+  constexpr int NCELL = RT / 32 > 1 ? RT / 32 : 1;  // cells (32 rows) a frequent column is cut into
+  constexpr int NHV = NCELL > 1 ? GPB / NCELL : 0;  // columns cut into cells: one cell per group
+  constexpr int PS = RT + kHotPosPad;    // bytes of a column's position row
+  double* Qs = hot + H * hot_w;
+  double* part = Qs + RT * KS;           // [GPB][k+2] cell sums (NCELL > 1)
+  unsigned int* hbits = reinterpret_cast<unsigned int*>(part + (NCELL > 1 ? GPB * hot_w : 0));
+  uint8_t* hpos = reinterpret_cast<uint8_t*>(hbits + ((H * NW + 1) & ~1));
   const double w0 = a.w0[0];
   const int64_t last_row = a.n_rows - 1;
   double loss_acc = 0.0, err_acc = 0.0;
@@ -201,6 +243,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
 
   if (H > 0) {
     for (int i = tid; i < H * hot_w; i += BLOCK) hot[i] = 0.0;
+    if (FIX)
+      for (int i = tid; i < H * NW; i += BLOCK) hbits[i] = 0u;
     __syncthreads();
   }
 
@@ -339,7 +383,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
       const int cnt = (maxlen - pb) < LPR ? (maxlen - pb) : LPR;
       // entries whose gathers are in flight together: the many-rows shape is at its register
       // budget with two (x R rows); the one-row shape has registers to spare
-#pragma unroll(BLOCK == kBigBlock || NC > 1 ? (NC == 1 && (ELL || !REC) ? RFM_FWD_BIG_UNROLL : 2) : RFM_FWD_SMALL_UNROLL)
+#pragma unroll(BLOCK == kBigBlock || NC > 1 ? (NC == 1 && !DET && (ELL || !REC) ? RFM_FWD_BIG_UNROLL : 2) : RFM_FWD_SMALL_UNROLL)
       for (int j = 0; j < cnt; ++j) {
         Entry ej[R];
         Pack<VEC> pv[R][NC];
@@ -426,11 +470,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
       // after the residual is known: marks of the sparse-class entries, and the hot
       // entries' err * x * [q, 1, x] into the workgroup's LDS sums.  A single round (rows
       // of at most LPR entries) still has its entries parked in LDS.
-      for (int pb = 0; pb < maxlen; pb += LPR) {
+      // (fixed-order hot sums meet at workgroup barriers: every group then makes the rounds
+      // of the plan's longest row, whatever its own rows need)
+      const bool fix_hot = FIX && H > 0 && RFM_KEEP(a, 32);
+      const int rounds_len = fix_hot ? a.hot_rounds * LPR : maxlen;
+      for (int pb = 0; pb < rounds_len; pb += LPR) {
         Entry em[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          if (maxlen > LPR) {  // (never in the padded form)
+          if (rounds_len > LPR) {  // (never in the padded form)
             em[i] = a.ent[len[i] > 0 ? p0[i] + min(pb + l, len[i] - 1) : 0];
             if (pb + l >= len[i]) em[i] = Entry{0, 0, 0.0};
             ebuf[i * LPR + l] = em[i];
@@ -451,6 +499,138 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
           }
         }
         if (!(H > 0 && RFM_KEEP(a, 32))) continue;
+        if constexpr (FIX) {
+          // ---- park: Q rows (once), err * x * [1, x] in place of the entries, row sets ----
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            const int row = i * GPB + g;
+            if (pb == 0 && fok[0]) {
+              Pack<VEC> pq;
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) pq.v[v] = q[i][0][v];
+              pq.store(Qs + row * KS + fo[0]);
+            }
+            const bool live = pb + l < len[i];
+            if (live && em[i].slot < 0) {
+              const int h = -1 - em[i].slot;
+              atomicOr(&hbits[h * NW + (row >> 5)], 1u << (row & 31));
+              hpos[h * PS + row] = uint8_t(l);
+            }
+            const double coef = live ? err[i] * em[i].x : 0.0;
+            Pack<2> pc;
+            pc.v[0] = coef;
+            pc.v[1] = coef * em[i].x;
+            pc.store(reinterpret_cast<double*>(ebuf + i * LPR + l));
+          }
+          __syncthreads();
+          if (RFM_KEEP(a, 8)) {
+            const Entry* ebase = reinterpret_cast<const Entry*>(dyn_lds + BLOCK);
+            // sum of err * x * [q, 1, x] over the rows of a set (lo: rows base.., hi: rows
+            // base + 64..), ascending; U rows' LDS reads are in flight together
+            double acc[VEC], accw, accx;
+            const auto add_rows = [&](int h, unsigned long long lo, unsigned long long hi, int base) {
+              while (lo | hi) {
+                constexpr int U = RFM_HOT_U;
+                int rowu[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                  ok[u] = (lo | hi) != 0;
+                  int bit = 0;
+                  if (lo) {
+                    bit = __builtin_ctzll(lo);
+                    lo &= lo - 1;
+                  } else if (hi) {
+                    bit = 64 + __builtin_ctzll(hi);
+                    hi &= hi - 1;
+                  }
+                  rowu[u] = base + bit;
+                }
+                int ju[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) ju[u] = hpos[h * PS + rowu[u]] & (LPR - 1);
+                Pack<2> cf[U];
+                Pack<VEC> qv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                  const int gg = rowu[u] % GPB, ii = rowu[u] / GPB;
+                  cf[u].load(reinterpret_cast<const double*>(ebase + gg * (R * LPR + 1) + ii * LPR + ju[u]));
+                  qv[u].load(Qs + rowu[u] * KS + fo[0]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                  if (ok[u]) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] += cf[u].v[0] * qv[u].v[v];
+                    accw += cf[u].v[0];
+                    accx += cf[u].v[1];
+                  }
+                }
+              }
+            };
+            const auto clear_acc = [&] {
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
+              accw = 0.0;
+              accx = 0.0;
+            };
+            const auto add_to = [&](double* row_out, bool overwrite) {
+              if (fok[0]) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                  row_out[fo[0] + v] = overwrite ? acc[v] : row_out[fo[0] + v] + acc[v];
+              }
+              if (l == 0) {
+                row_out[k] = overwrite ? accw : row_out[k] + accw;
+                row_out[k + 1] = overwrite ? accx : row_out[k + 1] + accx;
+              }
+            };
+            // the NHV most frequent columns are cut into cells of 32 rows, one per lane group:
+            // a cell's sum goes to its own row of `part`, combined in cell order below
+            if (NCELL > 1 && g / NCELL < H) {
+              const int h = g / NCELL, cell = g % NCELL;
+              const unsigned int word = hbits[h * NW + cell];
+              if (l == 0) hbits[h * NW + cell] = 0u;  // (the group has read it: one wave)
+              clear_acc();
+              add_rows(h, word, 0ull, cell * 32);
+              add_to(part + g * hot_w, true);
+            }
+            // the other columns: one lane group each, dealt boustrophedon over the ranks (which
+            // descend by frequency), starting opposite to the cells' order
+            for (int s2 = 0; NHV + s2 * GPB < H; ++s2) {
+              const int h = NHV + s2 * GPB + ((s2 & 1) ? g : GPB - 1 - g);
+              if (h >= H) continue;
+              unsigned long long lo = 0, hi = 0;
+#pragma unroll
+              for (int wi = 0; wi < NW; ++wi) {
+                const unsigned long long word = hbits[h * NW + wi];
+                if (wi < 2)
+                  lo |= word << (32 * wi);
+                else
+                  hi |= word << (32 * (wi - 2));
+              }
+              if ((lo | hi) == 0) continue;
+              if (l < NW) hbits[h * NW + l] = 0u;
+              clear_acc();
+              add_rows(h, lo, hi, 0);
+              add_to(hot + h * hot_w, false);
+            }
+          }
+          __syncthreads();  // the next round / trip rewrites the entries
+          if (NCELL > 1 && RFM_KEEP(a, 8)) {
+            // cells of a column, in cell order (lane group h: nobody else touches hot[h])
+            if (g < NHV && g < H) {
+              double* hrow = hot + g * hot_w;
+              for (int f = l; f < hot_w; f += LPR) {
+                double sum = hrow[f];
+#pragma unroll
+                for (int c = 0; c < NCELL; ++c) sum += part[(g * NCELL + c) * hot_w + f];
+                hrow[f] = sum;
+              }
+            }
+          }
+          continue;
+        }
         const int cnt = (maxlen - pb) < LPR ? (maxlen - pb) : LPR;
         // the lane groups of a wave start at different entries: rows of one log
         // tend to hold the same hot column at the same position, and adds to one

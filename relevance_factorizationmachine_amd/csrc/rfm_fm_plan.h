@@ -14,6 +14,8 @@ struct rfm_fm_plan {
   int32_t task_words = 1;     // 64-slot words per task
   int32_t n_split_short = 0, n_split_long = 0, n_parts = 0, n_hot = 0;
   int32_t max_row_len = 0;  // entries of the longest row of the log
+  int32_t hot_rounds = 1;  // rounds of a lane group's entries that cover the longest row
+  bool hot_fixed = false;  // hot-class sums in a fixed order (hot_min_count = -2)
   int64_t step = 0;  // stamps the partial rows of a step
   int32_t fwd_grid_max = 0;  // forward workgroups of a max_batch step (= hot-sum slabs)
   rfm::DevBuf ell;            // padded row blocks (every row <= lanes-per-group entries), else empty
@@ -43,6 +45,7 @@ namespace rfm {
 // reduction scratch and the 33 KiB entry buffer of the 1024-thread shape: gfx950 gives a
 // workgroup up to 160 KiB)
 constexpr size_t kHotLdsBudget = 56 << 10;
+constexpr size_t kHotLdsBudgetFixed = 40 << 10;  // ... when the fixed-order form shares the LDS
 constexpr int kMaxHot = 160;  // beyond this the slab traffic outweighs what the class saves
 constexpr int32_t kDefaultHotMinCount = 32;
 constexpr int32_t kShortSplit = 8;   // split columns up to this many partial rows: one lane group
@@ -60,5 +63,7 @@ inline int env_int(const char* name, int dflt) {
 int forward_grid(const rfm_ctx* ctx, int64_t rows, int n_factors);
 // whether that forward takes the many-rows-in-flight shape
 bool forward_many_rows(const rfm_ctx* ctx, int64_t rows, int n_factors);
+// the forward shapes a plan with this max_batch can take are built for fixed-order hot sums
+bool forward_fixed_order_ok(const rfm_ctx* ctx, int64_t max_batch, int n_factors);
 
 }  // namespace rfm

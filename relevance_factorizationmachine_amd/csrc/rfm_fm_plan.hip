@@ -216,7 +216,11 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
   // hot class: expected entries per batch >= hot_min, most frequent first, LDS budget
   std::vector<int32_t> hot_cols;
   std::vector<int32_t> hot_rank(nf, -1);
-  if (hot_min_count >= 0) {
+  // hot_min_count = -2: the hot class at its default threshold with FIXED-ORDER sums, where
+  // the forward shapes this plan can take are built for them; otherwise as -1 (no hot class)
+  const bool fixed = hot_min_count == -2 && forward_fixed_order_ok(ctx, max_batch, n_factors) &&
+                     env_int("RFM_NO_FIXED_HOT", 0) == 0;
+  if (hot_min_count >= 0 || fixed) {
     const int64_t hot_min = hot_min_count > 0 ? hot_min_count : kDefaultHotMinCount;
     for (size_t c = 0; c < nf; ++c)
       if (len(c) * max_batch >= hot_min * n_rows) hot_cols.push_back(int32_t(c));
@@ -224,10 +228,11 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
                      [&](int32_t x, int32_t y) { return len(size_t(x)) > len(size_t(y)); });
     const size_t per_col = size_t(n_factors + 2) * 8;
     // RFM_HOT_LDS_KB / RFM_MAX_HOT override the budget (tuning experiments only)
-    const size_t budget = size_t(env_int("RFM_HOT_LDS_KB", int(kHotLdsBudget >> 10))) << 10;
+    // (the fixed-order form parks a trip's Q rows, row sets and cell sums in LDS as well)
+    const size_t budget = size_t(env_int("RFM_HOT_LDS_KB", int((fixed ? kHotLdsBudgetFixed : kHotLdsBudget) >> 10))) << 10;
     const size_t cap = std::min<size_t>(size_t(env_int("RFM_MAX_HOT", kMaxHot)), budget / per_col);
     if (hot_cols.size() > cap) hot_cols.resize(cap);
-    std::sort(hot_cols.begin(), hot_cols.end());
+    // (ranks descend by frequency: the forward deals the columns to its lane groups by rank)
     for (size_t h = 0; h < hot_cols.size(); ++h) hot_rank[size_t(hot_cols[h])] = int32_t(h);
   }
   // tasks of fm_consume_kernel: the slot view is cut into tasks of task_words x 64 slots, one
@@ -316,6 +321,7 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
   plan->n_split_long = int32_t(split_long.size());
   plan->n_parts = n_parts;
   plan->n_hot = int32_t(hot_cols.size());
+  plan->hot_fixed = fixed && !hot_cols.empty();
   plan->h_hot_cols = hot_cols;
   plan->fwd_grid_max = forward_grid(ctx, max_batch, n_factors);
   DevBuf d_colinfo;
@@ -337,6 +343,7 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
   // batches keep the plain records); the plain records are then not kept
   const int64_t max_len = h_flags[3];
   plan->max_row_len = int32_t(max_len);
+  plan->hot_rounds = int32_t(std::max<int64_t>(1, (max_len + shp.lpr - 1) / shp.lpr));
   if (nnz > 0 && max_len <= shp.lpr && forward_many_rows(ctx, max_batch, n_factors) &&
       env_int("RFM_NO_ELL", 0) == 0) {
     plan->ell_stride = int64_t(shp.lpr) * int64_t(sizeof(Entry));

@@ -139,11 +139,12 @@ class FactorizationMachines(PointwiseBaseRecommender):
     evaluator: Optional[object] = None
 
     # Not a constructor argument: columns with at least this many expected
-    # entries per batch are summed on chip (0 = library default, -1 = never,
-    # which makes every sum's order fixed and a fit bitwise reproducible).
+    # entries per batch are summed on chip (0 = library default; -1 = never, which makes
+    # every sum's order fixed and a fit bitwise reproducible; -2 = the default columns, summed
+    # on chip in a fixed order: rfm_hip.h).
     hot_min_count = 0
-    # Not a constructor argument: True = every sum in a fixed order, i.e. hot_min_count = -1
-    # (a fit is then bitwise reproducible, at 1.4-2.8x the step time on KuaiRec-shaped logs).
+    # Not a constructor argument: True = every sum in a fixed order, i.e. hot_min_count = -2
+    # (a fit is then bitwise reproducible, at 1.1-1.25x the step time on KuaiRec-shaped logs).
     deterministic = False
     # Not a constructor argument: a ValEvaluator-like ``evaluator`` (see evaluate.py) is
     # computed on the device; False keeps the host callback for every evaluator.
@@ -194,7 +195,7 @@ class FactorizationMachines(PointwiseBaseRecommender):
               (rt.log_cache().get(val["features"]) if keep else DeviceCSR(rt, val["features"])))
         vy = rt.upload_cached(val["labels"], np.float64)
         vp = rt.upload_cached(val["pscores"], np.float64)
-        hot = -1 if self.deterministic else self.hot_min_count
+        hot = -2 if self.deterministic else self.hot_min_count
         plan = (plan_cache(rt).take(rt, tr, y, p, self.n_factors, self.batch_size, hot) if keep
                 else FmPlan(rt, tr, y, p, self.n_factors, self.batch_size, hot))
         self.plan_info = dict(plan.info(), **plan.layout())  # (what the last fit trained with)

@@ -246,7 +246,7 @@ def test_fm_forward_all_factor_counts(rfm, k):
     assert rel_err(model.predict(log["features"]), cpu_ref.fm_predict(log["features"], w0, w, V)) < TIGHT
 
 
-@pytest.mark.parametrize("hot", [0, -1, 4])
+@pytest.mark.parametrize("hot", [0, -1, -2, 4])
 @pytest.mark.parametrize("k,batch,dense_cols", [(3, 64, 0), (8, 500, 2), (32, 6000, 3), (64, 999, 1), (300, 128, 1)])
 def test_fm_fit_ragged_logs(rfm, k, batch, dense_cols, hot):
     """Variable nnz per row, empty rows, columns nobody touches, column lists
@@ -268,7 +268,7 @@ def test_fm_fit_ragged_logs(rfm, k, batch, dense_cols, hot):
     assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
 
 
-@pytest.mark.parametrize("hot", [0, -1])
+@pytest.mark.parametrize("hot", [0, -1, -2])
 @pytest.mark.parametrize("k,density,dense_cols", [(3, 0.04, 1), (32, 0.25, 4), (33, 0.05, 0), (96, 0.05, 2),
                                                   (200, 0.03, 1)])
 def test_fm_fit_full_chip_batches(rfm, k, density, dense_cols, hot):
@@ -311,7 +311,7 @@ def _bounded_log(rng, n_rows, n_cols, max_len, dense_cols):
     return {"features": X, "labels": y, "pscores": p}
 
 
-@pytest.mark.parametrize("hot", [0, -1])
+@pytest.mark.parametrize("hot", [0, -1, -2])
 @pytest.mark.parametrize("k,max_len,n_rows", [(4, 4, 140_000), (8, 4, 72_000), (16, 8, 72_000), (30, 16, 40_000),
                                               (64, 20, 24_000), (97, 33, 12_000), (128, 64, 12_000),
                                               (200, 40, 12_000), (7, 5, 72_000), (33, 30, 12_000)])
@@ -479,7 +479,7 @@ def big_log():
     return sh, train, val
 
 
-@pytest.mark.parametrize("hot", [0, -1])
+@pytest.mark.parametrize("hot", [0, -1, -2])
 @pytest.mark.parametrize("batch", [2000, 65536])
 def test_full_size_step_properties(rfm, big_log, batch, hot):
     """At BASELINE's full size the oracle is too slow for whole fits, so check
@@ -497,7 +497,7 @@ def test_full_size_step_properties(rfm, big_log, batch, hot):
     y = rt.upload(train["labels"], dtype=np.float64)
     p = rt.upload(train["pscores"], dtype=np.float64)
     plan = FmPlan(rt, dev, train["labels"], train["pscores"], k, batch, hot)
-    assert (plan.info()["hot_columns"] > 0) == (hot == 0)
+    assert (plan.info()["hot_columns"] > 0) == (hot in (0, -2))  # (-2: on chip, in a fixed order)
     ids_h = runtime.sample_batches(dev.shape[0], batch, 0, 1)[0]
     ids = rt.upload(ids_h)
     csr = (dev.indptr.data_ptr(), dev.indices.data_ptr(), dev.values.data_ptr(), y.data_ptr(), p.data_ptr())
@@ -856,20 +856,28 @@ def test_plan_builders_agree_and_reject_malformed_logs(rfm):
     rt.lib.rfm_fm_plan_destroy(empty)
 
 
-def test_deterministic_switch_gives_bitwise_reproducible_fits(rfm):
-    """model.deterministic = True (hot_min_count = -1): every sum has a fixed order, two fits are
-    equal bit for bit; the default (hot columns summed with LDS atomics) agrees to ~1e-13."""
+@pytest.mark.parametrize("shape,k,batch,n_train", [("kuairec_small", 16, 2000, None), ("kuairec_big", 32, 40_000, 120_000),
+                                                   ("kuairec_big", 64, 30_000, 100_000), ("kuairec_big", 7, 5000, 60_000)])
+def test_deterministic_switch_gives_bitwise_reproducible_fits(rfm, shape, k, batch, n_train):
+    """model.deterministic = True (hot_min_count = -2): the frequent columns are still summed on
+    chip, but in a fixed order (or, where the factor count has no such kernel, through their
+    column lists): two fits are equal bit for bit, at the one-row and the many-rows forward
+    shape; the default (LDS atomics) agrees to ~1e-12, and so does the oracle."""
     pkg = rfm[0]
-    train, val = synth.make_log("kuairec_small", "FM", "IPS", seed=0)
-    kw = dict(estimator="IPS", n_epochs=4, n_factors=16, lr=9e-6, batch_size=2000, seed=12345,
+    train, val = synth.make_log(shape, "FM", "IPS", seed=0, **({"n_train": n_train, "n_val": 500} if n_train else {}))
+    kw = dict(estimator="IPS", n_epochs=3, n_factors=k, lr=9e-6, batch_size=batch, seed=12345,
               n_features=train["features"].shape[1])
     fits = []
     for det in (True, True, False):
         m = pkg.FactorizationMachines(**kw)
         m.deterministic = det
         tr, va = m.fit(train, val)
-        fits.append((m.V(), m.w(), tr, va))
+        fits.append((m.V(), m.w(), tr, va, m.plan_info))
+    assert fits[0][4]["hot_columns"] > 0  # (the class is on in this mode)
     np.testing.assert_array_equal(fits[0][0], fits[1][0])
     np.testing.assert_array_equal(fits[0][1], fits[1][1])
     assert fits[0][2] == fits[1][2] and fits[0][3] == fits[1][3]
     assert rel_err(fits[2][0], fits[0][0]) < 1e-12 and rel_err(fits[2][2], fits[0][2]) < 1e-12
+    ref = cpu_ref.fm_fit(train, val, n_epochs=3, n_factors=k, lr=9e-6, batch_size=batch, seed=12345)
+    assert rel_err(fits[0][0], ref["V"]) < TIGHT and rel_err(fits[0][1], ref["w"]) < TIGHT
+    assert rel_err(fits[0][2], ref["train_loss"]) < TIGHT and rel_err(fits[0][3], ref["val_loss"]) < TIGHT

@@ -534,6 +534,33 @@ def main() -> None:
         out["sampler"] = {"host_exact_mt19937_s_per_batch": sampler_s / n_batches,
                           "threads": min(os.cpu_count() or 1, 32)}
         if not args.no_extra:
+            # the bitwise-reproducible mode (hot sums on chip in a fixed order: hot_min_count = -2)
+            det = {}
+            for db in sorted({B, 2000}):
+                if db > n_train:
+                    continue
+                pland = FmPlan(rt, csr, y, p, k, db, -2)
+                idsd = rt.upload(sample_batches(n_train, db, 0, 60))
+
+                def rund(first, count):
+                    _lib.check(rt.lib.rfm_fm_train(rt.ctx, pland.handle, *csr_ptrs,
+                                                   idsd.data_ptr() + first * db * 4, db, count,
+                                                   *params, lr, None, None, None, None, None, 0, 1e-8, None, None))
+                rund(0, 10)
+                rd = []
+                for _ in range(5):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    rund(10, 50)
+                    torch.cuda.synchronize()
+                    rd.append((time.perf_counter() - t0) / 50)
+                det[f"batch_{db}"] = {"ms_per_step": 1e3 * float(np.median(rd)),
+                                      "value": db / float(np.median(rd)), "unit": "examples/s",
+                                      "hot_columns": pland.info()["hot_columns"]}
+                pland.close()
+            out["extra"]["deterministic_mode"] = {
+                **det, "what": "model.deterministic = True: every sum of a step in a fixed order, fits equal "
+                               "bit for bit; the default sums the frequent columns with LDS float atomics"}
             if B != 2000:
                 # the reference's own batch size (conf/setting/kuairec.yaml:52)
                 plan2 = FmPlan(rt, csr, y, p, k, 2000)

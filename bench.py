@@ -234,6 +234,101 @@ def cpu_fit_wall(train, val, k, lr, seed, batch, n_epochs):
             "value": n_epochs * batch / dt, "unit": "examples/s"}
 
 
+# the reference's published runs (examples / wall of the run's log
+# interval -- derived, hardware unstated, an upper bound on fit() time)
+PUBLISHED = (
+    # name, synthetic shape, k, B, lr, iterations, reference examples/s, source
+    ("kuairec_fm_ips", "kuairec_small", 400, 2000, 9e-6, 221, 442000 / 137.3,
+     "logs/kuairec/main_kuairec.log:24-25 + data/best_params/kuairec/FM_IPS.json"),
+    ("coat_fm_ips", "coat", 300, 500, 1e-4, 401, 200500 / 63.4,
+     "logs/coat/main_coat.log:19-20 + data/best_params/coat/FM_IPS.json"),
+)
+
+
+def published_config(rt, only: str | None = None) -> dict:
+    """``extra.published_config``: the operating point of every published run of the reference
+    (conf/setting/kuairec.yaml:50-59: k=400, B=2000; coat.yaml:27-36: k=300, B=500) on the
+    synthetic log of that shape -- step-only (ids precomputed, as ``value``), per-kernel HIP-event
+    averages, and the fit() wall exactly as the reference runs it, next to the examples/s
+    derived from the reference's own run logs."""
+    import torch
+
+    from relevance_factorizationmachine_amd import _lib, synth
+    from relevance_factorizationmachine_amd.fm import FactorizationMachines, FmPlan
+    from relevance_factorizationmachine_amd.runtime import DeviceCSR, sample_batches
+
+    out = {}
+    for name, shape_name, k, B, lr, its, ref_ex_s, src in PUBLISHED:
+        if only and only != name:
+            continue
+        train, val = synth.make_log(shape_name, "FM", "IPS", seed=0)
+        X = train["features"]
+        n, z = X.shape[1], X.nnz / X.shape[0]
+        model = FactorizationMachines(estimator="IPS", n_epochs=its, n_factors=k, lr=lr, batch_size=B,
+                                      seed=12345, n_features=n)
+        csr = DeviceCSR(rt, X)
+        y = rt.upload(train["labels"], dtype=np.float64)
+        p = rt.upload(train["pscores"], dtype=np.float64)
+        plan = FmPlan(rt, csr, y, p, k, B)
+        warm, K = 20, 200
+        d_ids = rt.upload(sample_batches(X.shape[0], B, 0, warm + K))
+        args = (csr.indptr.data_ptr(), csr.indices.data_ptr(), csr.values.data_ptr(), y.data_ptr(), p.data_ptr())
+        params = (model.w0.dev.data_ptr(), model.w.dev.data_ptr(), model.V.dev.data_ptr())
+
+        def run(first, count):
+            _lib.check(rt.lib.rfm_fm_train(rt.ctx, plan.handle, *args, d_ids.data_ptr() + first * B * 4, B, count,
+                                           *params, lr, None, None, None, None, None, 0, 1e-8, None, None))
+        run(0, warm)
+        reg = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(warm, K)
+            torch.cuda.synchronize()
+            reg.append((time.perf_counter() - t0) / K)
+        dt = float(np.median(reg))
+        ms = (C.c_double * 4)()
+        cnt = (C.c_int64 * 4)()
+        _lib.check(rt.lib.rfm_profile_begin(rt.ctx))
+        run(warm, K)
+        _lib.check(rt.lib.rfm_profile_end(rt.ctx, ms, cnt))
+        info = plan.info()
+        split = info["split_columns"] > 0
+        fwd_b, upd_b = algorithmic_bytes(z, k)
+        plan.close()
+        # fit() exactly as the reference runs it (both loss forwards per iteration)
+        walls = {}
+        kw = dict(estimator="IPS", n_factors=k, lr=lr, seed=12345, n_features=n, batch_size=B)
+        FactorizationMachines(n_epochs=3, **kw).fit(train, val)
+        for state in ("cold", "again"):
+            if state == "cold":
+                rt.clear_caches()
+            m = FactorizationMachines(n_epochs=its, **kw)
+            t0 = time.perf_counter()
+            m.fit(train, val)
+            walls[state] = time.perf_counter() - t0
+        out[name] = {
+            "workload": f"{shape_name}-shaped synthetic log, n_features={n}, {z:.0f} nnz/row, N_train={X.shape[0]}, "
+                        f"N_val={val['features'].shape[0]}, FM k={k}, IPS, lr={lr}, batch_size={B}",
+            "V_bytes": n * k * 8,
+            "step": {"ms_per_step": 1e3 * dt, "value": B / dt, "unit": "examples/s",
+                     "kernels_avg_ms": dict(zip(STEP_KERNELS, [ms[i] / max(cnt[i], 1) if i < 2 or split else 0.0
+                                                              for i in range(3)])),
+                     "hot_columns": info["hot_columns"], "tasks": info["tasks"], "task_words": info["task_words"],
+                     "algorithmic_bytes_per_step": (fwd_b + upd_b) * B,
+                     "algorithmic_frac_of_hbm_peak": (fwd_b + upd_b) * B / dt / 1e9 / HBM_PEAK_GBS},
+            "fit_wall": {"iterations": its, "ms_per_iteration": 1e3 * walls["cold"] / its,
+                         "value": its * B / walls["cold"], "unit": "examples/s",
+                         "ms_per_iteration_second_fit_same_log": 1e3 * walls["again"] / its,
+                         "value_second_fit_same_log": its * B / walls["again"]},
+            "reference": {"value": ref_ex_s, "unit": "examples/s", "source": src,
+                          "note": "derived from the reference's committed run log (interval of the whole "
+                                  "load+fit+predict+evaluate block, hardware unstated): an upper bound on fit() time"},
+            "vs_baseline": its * B / walls["cold"] / ref_ex_s,
+        }
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,9 +356,18 @@ def main() -> None:
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes")
     ap.add_argument("--pmc-timeout", type=int, default=240)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--published-only", default=None, metavar="NAME|all",
+                    help="run only extra.published_config (kuairec_fm_ips, coat_fm_ips or all) and print it: "
+                         "the command the rocprofv3 profiles of the published operating point are taken from")
     args = ap.parse_args()
     if args.pmc_child:
         args.no_cpu_baseline = args.no_extra = args.no_pmc = True
+
+    if args.published_only:
+        from relevance_factorizationmachine_amd.runtime import Runtime
+        res = published_config(Runtime.get(0), None if args.published_only == "all" else args.published_only)
+        print(json.dumps({"published_config": res}))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -590,6 +694,7 @@ def main() -> None:
                     "event_pair_gap_ms": None if plan2_split else ms[2] / max(cnt[2], 1),
                     "algorithmic_frac": (fwd_b + upd_b) * 2000 / dt / 1e9 / HBM_PEAK_GBS}
                 plan2.close()
+            out["extra"]["published_config"] = published_config(rt)
             # variant (A): fit() exactly as the reference runs it (src/fm.py:71-102)
             fit = {}
             kw = dict(estimator="IPS", n_factors=k, lr=lr, seed=seed, n_features=n)

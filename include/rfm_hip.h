@@ -86,6 +86,13 @@ int32_t rfm_profile_end(rfm_ctx* ctx, double* h_ms, int64_t* h_count);
 int32_t rfm_sample_batches(int64_t n_rows, int64_t batch_size, int64_t epoch_begin,
                            int64_t n_epochs, int32_t* h_out_ids, int32_t n_threads);
 
+/* ---- content fingerprint of a host buffer (host) -------------------------
+ * Not on the reference's path: the reference reads its inputs on every fit()
+ * (src/fm.py:72-79 gathers from train["features"] each iteration); this library keeps device
+ * copies of a split between fits and re-uploads when this 64-bit hash of ALL bytes of the
+ * host array differs.  Independent of n_threads. */
+int32_t rfm_hash_bytes(const void* h_data, int64_t n_bytes, int32_t n_threads, uint64_t* h_out);
+
 /* ---- FM: forward / scores ----------------------------------------------
  * Replaces FactorizationMachines.predict (src/fm.py:114-133) with _sigmoid
  * (src/base.py:63-66): out[t] = sigmoid(clip(w0 + sum_i w_i x_ti

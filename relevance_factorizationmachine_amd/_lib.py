@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("RFM_LIB_PATH") or os.path.join(PKG_DIR, "librfm_hip.s
 SOURCES = ["rfm_capi.hip", "rfm_fm.hip", "rfm_fm_plan.hip", "rfm_mf.hip", "rfm_eval.hip", "rfm_csr.hip", "rfm_host.cpp", "rfm_comm.cpp"]
 HEADERS = [os.path.join(CSRC, "rfm_common.h"), os.path.join(CSRC, "rfm_fm_kernels.hpp"),
            os.path.join(CSRC, "rfm_fm_rows.hpp"), os.path.join(CSRC, "rfm_fm_plan.h"),
-           os.path.join(CSRC, "rfm_fm_records.h"),
+           os.path.join(CSRC, "rfm_fm_records.h"), os.path.join(CSRC, "rfm_device_utils.hpp"),
            os.path.join(os.path.dirname(PKG_DIR), "include", "rfm_hip.h")]
 
 RFM_OK, RFM_ERR_BAD_ARG, RFM_ERR_HIP, RFM_ERR_NO_DEVICE, RFM_ERR_INTERNAL = range(5)
@@ -48,22 +48,50 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP extension for gfx950 in-tree; returns the .so path."""
+    """Compile the HIP extension for gfx950 in-tree; returns the .so path.  One object per
+    source file (compiled concurrently, kept under ``csrc/build/`` and reused while neither
+    the source nor a header is newer), then one link."""
     if not force and not _stale():
         return LIB_PATH
     hipcc = _hipcc()
     if hipcc is None:
         raise RfmError("hipcc not found: cannot build librfm_hip.so (set HIPCC or install ROCm)")
+    from concurrent.futures import ThreadPoolExecutor
+
+    obj_dir = os.path.join(CSRC, "build")
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"] + os.environ.get("RFM_HIPCC_FLAGS", "").split()
+    stamp = os.path.join(obj_dir, "flags.txt")
+    same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
+    hdr_time = max(os.path.getmtime(h) for h in HEADERS if os.path.exists(h))
+
+    def compile_one(src: str):
+        obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+        path = os.path.join(CSRC, src)
+        if (not force and same_flags and os.path.exists(obj)
+                and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time)):
+            return obj, None
+        cmd = [hipcc] + flags + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        return obj, (proc.stdout + proc.stderr) if proc.returncode != 0 else None
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        results = list(pool.map(compile_one, SOURCES))
+    errors = [msg for _, msg in results if msg]
+    if errors:
+        raise RfmError("building librfm_hip.so failed:\n" + "\n".join(errors))
+    open(stamp, "w").write(" ".join(flags))
     tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread", "-ldl"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp] + [o for o, _ in results] + ["-lpthread", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         if os.path.exists(tmp):
             os.remove(tmp)
-        raise RfmError("building librfm_hip.so failed:\n" + proc.stdout + proc.stderr)
+        raise RfmError("linking librfm_hip.so failed:\n" + proc.stdout + proc.stderr)
     os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
@@ -80,6 +108,7 @@ SIGNATURES = {
     "rfm_profile_begin": [_vp],
     "rfm_profile_end": [_vp, _vp, _vp],
     "rfm_sample_batches": [_i64, _i64, _i64, _i64, _vp, _i32],
+    "rfm_hash_bytes": [_vp, _i64, _i32, _vp],
     "rfm_fm_forward": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp],
     "rfm_ips_logloss": [_vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp],
     "rfm_fm_forward_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32,

@@ -18,6 +18,7 @@
 // hot-class sums inside one workgroup are LDS atomics, so their last bits may vary from run
 // to run (hot_min_count < 0 turns the class off).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -46,6 +47,7 @@ struct FwdGeom {
 #define RFM_FWD_SMALL_BLOCK 256
 #endif
 constexpr int kSmallBlock = RFM_FWD_SMALL_BLOCK;  // threads of the one-row-per-group shape
+constexpr int kMaxDevices = 64;  // devices of one process whose launch attributes are remembered
 
 inline FwdGeom forward_geom(const rfm_ctx* ctx, int64_t n_rows, const Shape& s, bool records) {
   static const int per_cu = std::max(1, env_int("RFM_FWD_PER_CU", kBigBlock >= 1024 ? 1 : 2));
@@ -81,11 +83,14 @@ bool forward_many_rows(const rfm_ctx* ctx, int64_t rows, int n_factors) {
 template <int L, int Vv, int N, int BLOCK, int R, bool REC, bool ELL, bool DET>
 void launch_forward_as(rfm_ctx* ctx, const FwdArgs& a, const FwdGeom& geom, size_t lds) {
   const auto kern = &fm_forward_kernel<L, Vv, N, BLOCK, R, REC, ELL, DET>;
-  static size_t lds_allowed = 64u << 10;
-  if (lds > lds_allowed) {
+  // (the attribute belongs to the function ON a device: kept per device; atomics because
+  // contexts of different host threads share the instantiation)
+  static std::atomic<size_t> lds_allowed[kMaxDevices];
+  const int dev = ctx->device >= 0 && ctx->device < kMaxDevices ? ctx->device : -1;
+  if (lds > (64u << 10) && (dev < 0 || lds > lds_allowed[dev].load(std::memory_order_relaxed))) {
     RFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-    lds_allowed = lds;
+    if (dev >= 0) lds_allowed[dev].store(lds, std::memory_order_relaxed);
   }
   hipLaunchKernelGGL(kern, dim3(geom.grid), dim3(BLOCK), lds, ctx->stream, a);
 }
@@ -106,13 +111,21 @@ void launch_forward_shape(rfm_ctx* ctx, const FwdArgs& a, const FwdGeom& geom, s
     }
     RFM_REQUIRE(!fixed, "fixed-order hot sums are not built for this factor count at this batch");
     if (a.ell) return launch_forward_as<L, Vv, N, kBigBlock, R, true, true, false>(ctx, a, geom, lds);
+    RFM_REQUIRE(a.ent && a.rows, "the plan holds no row records");
     return launch_forward_as<L, Vv, N, kBigBlock, R, true, false, false>(ctx, a, geom, lds);
   }
   if (!recs) return launch_forward_as<L, Vv, N, kSmallBlock, 1, false, false, false>(ctx, a, geom, lds);
+  // (a plan made for many-rows batches keeps only the padded row blocks: a step of fewer rows
+  // on it reads those too)
   if constexpr (hot_fixed_order(L, N, kSmallBlock, 1)) {
-    if (fixed) return launch_forward_as<L, Vv, N, kSmallBlock, 1, true, false, true>(ctx, a, geom, lds);
+    if (fixed) {
+      if (a.ell) return launch_forward_as<L, Vv, N, kSmallBlock, 1, true, true, true>(ctx, a, geom, lds);
+      return launch_forward_as<L, Vv, N, kSmallBlock, 1, true, false, true>(ctx, a, geom, lds);
+    }
   }
   RFM_REQUIRE(!fixed, "fixed-order hot sums are not built for this factor count");
+  if (a.ell) return launch_forward_as<L, Vv, N, kSmallBlock, 1, true, true, false>(ctx, a, geom, lds);
+  RFM_REQUIRE(a.ent && a.rows, "the plan holds no row records");
   return launch_forward_as<L, Vv, N, kSmallBlock, 1, true, false, false>(ctx, a, geom, lds);
 }
 
@@ -334,6 +347,67 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   }
   ctx->prof_mark();
 }
+
+// Timing experiment (RFM_TRAIN_GRAPH): everything enqueued on the context's stream while this
+// object lives is captured into one hipGraph on a stream of its own (the legacy default stream
+// cannot be captured) and run by replay().  Whatever happens in between -- an RFM_REQUIRE, a HIP
+// error -- the destructor ends the capture, restores ctx->stream and frees the stream.
+struct GraphCapture {
+  rfm_ctx* ctx;
+  hipStream_t user_stream = nullptr, cap_stream = nullptr;
+  bool capturing = false;
+  GraphCapture(rfm_ctx* c, bool on) : ctx(c) {
+    if (!on) return;
+    user_stream = ctx->stream;
+    RFM_HIP_CHECK(hipStreamSynchronize(user_stream));
+    RFM_HIP_CHECK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+    if (hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      (void)hipStreamDestroy(cap_stream);
+      cap_stream = nullptr;
+      fail(RFM_ERR_HIP, "hipStreamBeginCapture failed");
+    }
+    ctx->stream = cap_stream;
+    capturing = true;
+  }
+  GraphCapture(const GraphCapture&) = delete;
+  GraphCapture& operator=(const GraphCapture&) = delete;
+  hipGraph_t end() {
+    hipGraph_t graph = nullptr;
+    if (capturing) {
+      capturing = false;
+      ctx->stream = user_stream;
+      if (hipStreamEndCapture(cap_stream, &graph) != hipSuccess) graph = nullptr;
+    }
+    return graph;
+  }
+  void replay(int64_t n_iters) {
+    if (!cap_stream) return;
+    hipGraph_t graph = end();
+    RFM_REQUIRE(graph, "hipStreamEndCapture failed");
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+      (void)hipGraphDestroy(graph);
+      fail(RFM_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    }
+    const bool timed = env_int("RFM_TRAIN_GRAPH", 0) > 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t run = hipGraphLaunch(exec, cap_stream);
+    if (run == hipSuccess) run = hipStreamSynchronize(cap_stream);
+    if (timed && run == hipSuccess)
+      fprintf(stderr, "[rfm] graph of %lld iterations: %.2f us per iteration (launch to drain)\n",
+              (long long)n_iters,
+              std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() /
+                  double(std::max<int64_t>(n_iters, 1)));
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    RFM_HIP_CHECK(run);
+  }
+  ~GraphCapture() {
+    if (hipGraph_t graph = end()) (void)hipGraphDestroy(graph);
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
+  }
+};
 
 FwdArgs forward_args(const int64_t* d_indptr, const int32_t* d_indices, const double* d_values,
                      const int32_t* d_row_ids, int64_t n_rows, const double* d_w0,
@@ -636,16 +710,10 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
                            val_rows, int64_t(kMaxFwdGrid), val_parts, n_val, d_out_val_loss + first);
       RFM_HIP_CHECK(hipGetLastError());
     };
-    // RFM_TRAIN_GRAPH=1 (timing experiment): the run's launches captured into one hipGraph on
-    // a stream of its own (the legacy default stream cannot be captured) and replayed once
+    // RFM_TRAIN_GRAPH=1 (timing experiment): the run's launches captured into one hipGraph
+    // and replayed once (GraphCapture restores the context's stream on every way out)
     static const bool as_graph = env_int("RFM_TRAIN_GRAPH", 0) != 0;
-    hipStream_t user_stream = ctx->stream, cap_stream = nullptr;
-    if (as_graph && !ctx->profiling) {
-      RFM_HIP_CHECK(hipStreamSynchronize(user_stream));
-      RFM_HIP_CHECK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
-      ctx->stream = cap_stream;
-      RFM_HIP_CHECK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
-    }
+    GraphCapture capture(ctx, as_graph && !ctx->profiling);
     int64_t run_first = 0;
     for (int64_t it = 0; it < n_iters; ++it) {
       const int32_t* ids = d_ids + it * batch;
@@ -683,25 +751,7 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
       }
     }
     finish(run_first, n_iters - run_first);
-    if (cap_stream) {
-      hipGraph_t graph = nullptr;
-      hipGraphExec_t exec = nullptr;
-      ctx->stream = user_stream;
-      RFM_HIP_CHECK(hipStreamEndCapture(cap_stream, &graph));
-      RFM_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-      static const bool timed = env_int("RFM_TRAIN_GRAPH", 0) > 1;
-      const auto t0 = std::chrono::steady_clock::now();
-      RFM_HIP_CHECK(hipGraphLaunch(exec, cap_stream));
-      RFM_HIP_CHECK(hipStreamSynchronize(cap_stream));
-      if (timed)
-        fprintf(stderr, "[rfm] graph of %lld iterations: %.2f us per iteration (launch to drain)\n",
-                (long long)n_iters,
-                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() /
-                    double(n_iters));
-      (void)hipGraphExecDestroy(exec);
-      (void)hipGraphDestroy(graph);
-      (void)hipStreamDestroy(cap_stream);
-    }
+    capture.replay(n_iters);
   });
 }
 

@@ -313,3 +313,74 @@ int32_t rfm_mf_schedule_ex(const int32_t* h_users, const int32_t* h_items, const
 }
 
 }  // extern "C"
+
+// --------------------------------------------------------------------------
+// 64-bit content fingerprint of a host buffer (what the upload caches compare before they
+// trust a device copy: EVERY byte is read).  The buffer is cut into 1 MiB pieces hashed by
+// the host threads -- four multiply-rotate lanes of 8 bytes each, the construction of the
+// published xxHash64 round -- and the pieces' hashes are folded in piece order, so the result
+// does not depend on the thread count.
+// --------------------------------------------------------------------------
+namespace rfm {
+namespace {
+constexpr uint64_t kP1 = 0x9E3779B185EBCA87ull, kP2 = 0xC2B2AE3D27D4EB4Full,
+                   kP3 = 0x165667B19E3779F9ull, kP4 = 0x85EBCA77C2B2AE63ull,
+                   kP5 = 0x27D4EB2F165667C5ull;
+inline uint64_t rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+inline uint64_t lane_round(uint64_t acc, uint64_t in) { return rotl(acc + in * kP2, 31) * kP1; }
+inline uint64_t avalanche(uint64_t h) {
+  h ^= h >> 33;
+  h *= kP2;
+  h ^= h >> 29;
+  h *= kP3;
+  h ^= h >> 32;
+  return h;
+}
+uint64_t hash_piece(const unsigned char* p, size_t n, uint64_t seed) {
+  uint64_t a = seed + kP1 + kP2, b = seed + kP2, c = seed, d = seed - kP1;
+  size_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    uint64_t w[4];
+    memcpy(w, p + i, 32);
+    a = lane_round(a, w[0]);
+    b = lane_round(b, w[1]);
+    c = lane_round(c, w[2]);
+    d = lane_round(d, w[3]);
+  }
+  uint64_t h = rotl(a, 1) + rotl(b, 7) + rotl(c, 12) + rotl(d, 18) + uint64_t(n);
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w;
+    memcpy(&w, p + i, 8);
+    h = rotl(h ^ lane_round(0, w), 27) * kP1 + kP4;
+  }
+  for (; i < n; ++i) h = rotl(h ^ (uint64_t(p[i]) * kP5), 11) * kP1;
+  return avalanche(h);
+}
+}  // namespace
+}  // namespace rfm
+
+extern "C" int32_t rfm_hash_bytes(const void* h_data, int64_t n_bytes, int32_t n_threads,
+                                  uint64_t* h_out) {
+  return rfm::guarded([&] {
+    RFM_REQUIRE(h_out && n_bytes >= 0 && (h_data || n_bytes == 0), "bad arguments");
+    constexpr int64_t kPiece = 1 << 20;
+    const int64_t n_pieces = (n_bytes + kPiece - 1) / kPiece;
+    std::vector<uint64_t> piece(size_t(std::max<int64_t>(n_pieces, 1)), 0);
+    const unsigned char* base = static_cast<const unsigned char*>(h_data);
+    const int threads = int(std::max<int64_t>(1, std::min<int64_t>(std::max(n_threads, 1), n_pieces)));
+    std::atomic<int64_t> next{0};
+    const auto work = [&] {
+      for (int64_t i = next.fetch_add(1); i < n_pieces; i = next.fetch_add(1)) {
+        const int64_t lo = i * kPiece, len = std::min<int64_t>(kPiece, n_bytes - lo);
+        piece[size_t(i)] = rfm::hash_piece(base + lo, size_t(len), uint64_t(i));
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    uint64_t h = rfm::kP5 + uint64_t(n_bytes);
+    for (int64_t i = 0; i < n_pieces; ++i) h = rfm::rotl(h ^ piece[size_t(i)], 27) * rfm::kP1 + rfm::kP4;
+    *h_out = rfm::avalanche(h);
+  });
+}

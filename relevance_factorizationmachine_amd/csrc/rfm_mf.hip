@@ -15,6 +15,7 @@
 #include <cmath>
 
 #include "rfm_common.h"
+#include "rfm_device_utils.hpp"
 
 namespace rfm {
 
@@ -23,56 +24,6 @@ constexpr int kMfBlock = 256;
 #define RFM_SEQ_BLOCK 1024
 #endif
 constexpr int kSeqBlock = RFM_SEQ_BLOCK;  // threads of the sequential workgroup
-constexpr double kMfLogitClip = 700.0;  // src/base.py:65
-
-// Sum over the LPR lanes of a lane group; every lane gets the total.  The steps
-// inside a row of 16 lanes are DPP moves (quad permutes, half-row and row mirrors:
-// a few cycles each) instead of ds_bpermute round trips through the LDS crossbar.
-template <int CTRL>
-__device__ inline double mf_dpp_move(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
-}
-
-template <int LPR>
-__device__ inline double mf_group_sum(double v) {
-  if (LPR >= 2) v += mf_dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
-  if (LPR >= 4) v += mf_dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
-  if (LPR >= 8) v += mf_dpp_move<0x141>(v);  // row_half_mirror
-  if (LPR >= 16) v += mf_dpp_move<0x140>(v); // row_mirror
-  if (LPR >= 32) v += __shfl_xor(v, 16, 64);
-  if (LPR >= 64) v += __shfl_xor(v, 32, 64);
-  return v;
-}
-
-template <int VEC>
-struct MfPack;
-template <>
-struct MfPack<1> {
-  double v[1];
-  __device__ inline void load(const double* p) { v[0] = *p; }
-  __device__ inline void store(double* p) const { *p = v[0]; }
-};
-template <>
-struct MfPack<2> {
-  double v[2];
-  __device__ inline void load(const double* p) {
-    const double2 t = *reinterpret_cast<const double2*>(p);
-    v[0] = t.x;
-    v[1] = t.y;
-  }
-  __device__ inline void store(double* p) const {
-    *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]);
-  }
-};
-
-__device__ inline double mf_sigmoid(double z) {
-  z = z != z ? z : fmin(fmax(z, -kMfLogitClip), kMfLogitClip);  // np.clip keeps NaN
-  return 1.0 / (1.0 + exp(-z));
-}
-
 struct MfPredArgs {
   const int32_t* users;
   const int32_t* items;
@@ -119,7 +70,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_predict_kernel(MfPredArgs a) {
       for (int c = 0; c < NC; ++c) {
         const int f = (c * LPR + l) * VEC;
         if (f < k) {
-          MfPack<VEC> pp, pq;
+          Pack<VEC> pp, pq;
           pp.load(pu + f);
           pq.load(qi + f);
 #pragma unroll
@@ -127,9 +78,9 @@ __global__ __launch_bounds__(kMfBlock) void mf_predict_kernel(MfPredArgs a) {
         }
       }
     }
-    dot = mf_group_sum<LPR>(dot);
+    dot = group_sum<LPR>(dot);
     if (valid && l == 0) {
-      const double pred = mf_sigmoid(dot + a.bu[u] + a.bi[i] + a.b);
+      const double pred = sigmoid_clipped(dot + a.bu[u] + a.bi[i] + a.b);
       if (a.out_pred) a.out_pred[t] = pred;
       if (a.loss_partial) {
         const double rr = a.y[r] / a.pscore[r];
@@ -191,7 +142,7 @@ __device__ inline void mf_example(const MfSgdArgs& a, int32_t s, int l) {
   const int32_t u = a.users[r], i = a.items[r];
   double* pu = a.P + int64_t(u) * k;
   double* qi = a.Q + int64_t(i) * k;
-  MfPack<VEC> pp[NC], pq[NC];
+  Pack<VEC> pp[NC], pq[NC];
   double dot = 0.0;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -203,9 +154,9 @@ __device__ inline void mf_example(const MfSgdArgs& a, int32_t s, int l) {
       for (int v = 0; v < VEC; ++v) dot += pp[c].v[v] * pq[c].v[v];
     }
   }
-  dot = mf_group_sum<LPR>(dot);
+  dot = group_sum<LPR>(dot);
   const double bu = a.bu[u], bi = a.bi[i];
-  const double err = a.y[r] / a.pscore[r] - mf_sigmoid(dot + bu + bi + a.b);
+  const double err = a.y[r] / a.pscore[r] - sigmoid_clipped(dot + bu + bi + a.b);
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int f = (c * LPR + l) * VEC;
@@ -283,7 +234,7 @@ struct MfExArgs {
 // the arithmetic of one example on rows already in registers (src/mf.py:99-108,
 // 172-216): returns the residual, rows and biases are updated in place
 template <int LPR, int VEC, int NC>
-__device__ inline void mf_update(MfPack<VEC> (&pp)[NC], MfPack<VEC> (&pq)[NC], double& bu,
+__device__ inline void mf_update(Pack<VEC> (&pp)[NC], Pack<VEC> (&pq)[NC], double& bu,
                                  double& bi, double ry, double b, double lr, double reg, int k,
                                  int l) {
   double dot = 0.0;
@@ -295,8 +246,8 @@ __device__ inline void mf_update(MfPack<VEC> (&pp)[NC], MfPack<VEC> (&pq)[NC], d
       for (int v = 0; v < VEC; ++v) dot += pp[c].v[v] * pq[c].v[v];
     }
   }
-  dot = mf_group_sum<LPR>(dot);
-  const double err = ry - mf_sigmoid(dot + bu + bi + b);
+  dot = group_sum<LPR>(dot);
+  const double err = ry - sigmoid_clipped(dot + bu + bi + b);
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -313,7 +264,7 @@ __device__ inline void mf_update(MfPack<VEC> (&pp)[NC], MfPack<VEC> (&pq)[NC], d
 }
 
 template <int LPR, int VEC, int NC>
-__device__ inline void mf_load_row(MfPack<VEC> (&dst)[NC], const double* row, int k, int l) {
+__device__ inline void mf_load_row(Pack<VEC> (&dst)[NC], const double* row, int k, int l) {
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int f = (c * LPR + l) * VEC;
@@ -322,7 +273,7 @@ __device__ inline void mf_load_row(MfPack<VEC> (&dst)[NC], const double* row, in
 }
 
 template <int LPR, int VEC, int NC>
-__device__ inline void mf_store_row(const MfPack<VEC> (&src)[NC], double* row, int k, int l) {
+__device__ inline void mf_store_row(const Pack<VEC> (&src)[NC], double* row, int k, int l) {
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int f = (c * LPR + l) * VEC;
@@ -340,7 +291,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_sgd_wide_ex_kernel(MfExArgs a) {
   for (int64_t idx = int64_t(a.lo) + int64_t(blockIdx.x) * GPB + g; idx < a.hi;
        idx += int64_t(gridDim.x) * GPB) {
     const MfEx e = a.ex[idx];
-    MfPack<VEC> pp[NC], pq[NC];
+    Pack<VEC> pp[NC], pq[NC];
     mf_load_row<LPR, VEC, NC>(pp, a.P + int64_t(e.u) * k, k, l);
     mf_load_row<LPR, VEC, NC>(pq, a.Q + int64_t(e.i) * k, k, l);
     double bu = a.bu[e.u], bi = a.bi[e.i];
@@ -383,7 +334,7 @@ struct MfSlot {
   bool has;       // this lane group has an example at the slot's level
   bool got_user;  // pp / bu hold the user row (final)
   bool got_item;  // pq / bi hold the item row (an item that occurs once in the batch)
-  MfPack<VEC> pp[NC], pq[NC];
+  Pack<VEC> pp[NC], pq[NC];
   double bu, bi;
 };
 

@@ -183,6 +183,14 @@ class FactorizationMachines(PointwiseBaseRecommender):
         # batch selection: resample(..., random_state=epoch) (src/fm.py:72-79), sampled on the
         # host chunk by chunk while the GPU trains on the chunk before
         id_stream = BatchIdStream(rt, n_rows, self.batch_size, self.n_epochs, need_host=False)
+        try:
+            return self._fit(train, val, id_stream)
+        finally:
+            id_stream.close()  # (its sampler thread runs from the constructor on)
+
+    def _fit(self, train: dict, val: dict, id_stream: BatchIdStream) -> tuple:
+        rt = self._rt
+        X = train["features"]
 
         # a log that is already in HBM (features.assemble / load_csr_to_device) is used as it is
         # (device copies of the split are remembered per device: the drivers fit several models

@@ -69,6 +69,12 @@ class _SchedulePipe:
             self.ready.put(None)
         except BaseException as exc:  # noqa: BLE001 -- handed to the consumer
             self.ready.put(exc)
+        finally:
+            # the generator runs id_stream.chunks() in THIS thread: closing it here runs that
+            # generator's cleanup (sampler thread stopped, pinned buffers released)
+            close = getattr(epochs, "close", None)
+            if close is not None:
+                close()
 
     def take(self):
         """Next iteration: enqueues the copy and returns ``(epoch, ids_ptr, device ex ptr, HOST
@@ -171,6 +177,13 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
         # resample(..., random_state=epoch) ids (src/mf.py:88-95), sampled chunk by chunk on
         # the host while the GPU works on the chunk before
         id_stream = BatchIdStream(rt, n_rows, self.batch_size, self.n_epochs)
+        try:
+            return self._fit(train, val, id_stream)
+        finally:
+            id_stream.close()  # (its sampler thread runs from the constructor on)
+
+    def _fit(self, train: dict, val: dict, id_stream: BatchIdStream) -> tuple:
+        rt = self._rt
         self._keep_ids = []
 
         tr = DevicePairs(rt, train["features"])

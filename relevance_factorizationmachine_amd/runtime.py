@@ -29,19 +29,23 @@ def ptr(t) -> Optional[int]:
     return t.data_ptr()
 
 
-def _sample_hash(arr: np.ndarray) -> int:
-    """Hash of both ends and of 16 384 evenly spaced elements of a 1-D array: what the upload
-    caches compare before they trust a device copy (an in-place edit of a whole array, or of
-    any sampled element, shows; a single edited element in between does not)."""
-    step = max(1, len(arr) // 16384)
-    return hash(np.concatenate([arr[:64], arr[::step], arr[-64:]]).tobytes())
+def content_hash(arr: np.ndarray) -> int:
+    """64-bit fingerprint of EVERY byte of a host array (``rfm_hash_bytes``: multi-threaded,
+    a few milliseconds per 100 MB): what the upload caches compare before they trust a device
+    copy, so that any in-place edit between two calls -- a single element included -- is seen
+    and the array uploaded again (the reference reads its inputs on every fit)."""
+    a = np.ascontiguousarray(arr)
+    out = C.c_uint64(0)
+    _lib.check(_lib.load().rfm_hash_bytes(a.ctypes.data, a.nbytes, min(os.cpu_count() or 1, 16), C.byref(out)))
+    return int(out.value)
 
 
 class Runtime:
     """One librfm context on one GPU, bound to torch's current stream."""
 
     # fit() keeps the device copies of the split it was given (features, labels,
-    # propensities) for the next fit on the same objects; False = upload every time
+    # propensities) for the next fit on the same objects WITH THE SAME CONTENTS (every byte is
+    # hashed on each call: content_hash); False = upload every time
     remember_splits = True
 
     _instances: Dict[int, "Runtime"] = {}
@@ -102,12 +106,12 @@ class Runtime:
 
     def upload_cached(self, a, dtype):
         """Device copy of a host vector (labels, propensities), remembered for the next
-        ``fit()`` on the same array object with the same contents (cheap sample check, as
+        ``fit()`` on the same array object with the same contents (hash of the whole array, as
         ``CsrCache``): the drivers fit several models on one split."""
         if not isinstance(a, np.ndarray) or a.size == 0 or not self.remember_splits:
             return self.upload(np.asarray(a), dtype=dtype)
         cache = self.__dict__.setdefault("_vec_cache", [])
-        key = (id(a), a.shape, a.dtype.str, np.dtype(dtype).str, _sample_hash(a.reshape(-1)))
+        key = (id(a), a.shape, a.dtype.str, np.dtype(dtype).str, content_hash(a))
         for ref, k, dev in cache:
             if k == key and ref() is a:
                 return dev
@@ -196,15 +200,15 @@ class CsrCache:
 
     @staticmethod
     def _fingerprint(X) -> tuple:
-        """Cheap content check: shape, nnz and a sample of the three CSR arrays (ends and a
-        stride through the middle), so that a matrix edited in place between two calls is
-        uploaded again instead of being scored from the stale device copy."""
+        """Content check: shape, nnz and a hash of ALL bytes of the three CSR arrays, so that a
+        matrix edited in place between two calls -- any element -- is uploaded again instead of
+        being scored from the stale device copy."""
         nnz = int(X.nnz)
         parts = [X.shape, nnz]
         for arr in (getattr(X, "data", None), getattr(X, "indices", None), getattr(X, "indptr", None)):
             if arr is None or not len(arr):
                 continue
-            parts.append(_sample_hash(arr))
+            parts.append(content_hash(arr))
         return tuple(parts)
 
     def get(self, X) -> DeviceCSR:
@@ -425,19 +429,26 @@ class BatchIdStream:
                     yield first, got, self.rt.upload(got)
             complete = True
         finally:
-            self._stop = True
-            if self._thread is not None:
-                while self._thread.is_alive():  # unblock a producer waiting on a full queue
-                    try:
-                        self._queue.get_nowait()
-                    except Exception:  # noqa: BLE001 -- empty
-                        self._thread.join(timeout=0.01)
-            if self._dev_all is not None:
-                for _, ev in self._staging:
-                    if ev is not None:
-                        ev.synchronize()
-                if complete:
-                    ID_CACHE.put_device(self.rt.device, self.n_rows, self.batch_size, self._dev_all)
+            self.close()
+            if complete and self._dev_all is not None:
+                ID_CACHE.put_device(self.rt.device, self.n_rows, self.batch_size, self._dev_all)
+
+    def close(self) -> None:
+        """Stop the sampler thread (it starts in the constructor, so a ``fit()`` that fails before
+        ``chunks()`` is iterated must call this) and wait for the copies out of the pinned
+        buffers.  Idempotent."""
+        self._stop = True
+        thread, self._thread = self._thread, None
+        if thread is not None:
+            while thread.is_alive():  # unblock a producer waiting on a full queue
+                try:
+                    self._queue.get_nowait()
+                except Exception:  # noqa: BLE001 -- empty
+                    thread.join(timeout=0.01)
+        if self._dev_all is not None and not self._resident:
+            for _, ev in self._staging:
+                if ev is not None:
+                    ev.synchronize()
 
 
 def mf_schedule(users: np.ndarray, items: np.ndarray, n_users: int, n_items: int):

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 from scipy.sparse import csr_matrix, random as sprandom
 
-from conftest import load_golden, rel_err
+from conftest import assert_elementwise, load_golden, rel_err
 from oracle import cpu_ref
 from relevance_factorizationmachine_amd import synth
 
@@ -62,6 +62,10 @@ def test_fm_fit_matches_reference_golden(rfm, fixture, shape, est):
     assert pred.dtype == np.float64 and pred.ndim == 1
     assert rel_err(pred, g[f"{est}_pred_val"]) < TIGHT
     assert rel_err(pred, g[f"{est}_pred_val"]) < CONTRACT
+    # ... and the contract tolerance element by element (|a-b| <= 1e-5 |b| + 1e-12)
+    for got, name in ((model.V(), "V"), (model.w(), "w"), (model.w0(), "w0"), (tr, "train_loss"),
+                      (va, "val_loss"), (pred, "pred_val")):
+        assert_elementwise(got, g[f"{est}_{name}"], what=f"{fixture} {est} {name}")
     np.testing.assert_array_equal(model.predict(val["features"]), pred)  # positional call too
 
 
@@ -83,6 +87,9 @@ def test_mf_fit_matches_reference_golden(rfm, est):
     assert rel_err(tr, g[f"{est}_train_loss"]) < TIGHT
     assert rel_err(va, g[f"{est}_val_loss"]) < TIGHT
     assert rel_err(model.predict(val["features"]), g[f"{est}_pred_val"]) < TIGHT
+    for got, name in ((model.P(), "P"), (model.Q(), "Q"), (model.b_u(), "b_u"), (model.b_i(), "b_i"),
+                      (tr, "train_loss"), (va, "val_loss"), (model.predict(val["features"]), "pred_val")):
+        assert_elementwise(got, g[f"{est}_{name}"], what=f"mf_small {est} {name}")
 
 
 def test_fit_with_ids_sampled_in_chunks(rfm):
@@ -149,6 +156,24 @@ def test_fit_remembers_the_split_and_notices_edits(rfm):
     train["features"].data *= 0.5
     m4 = _fm(pkg, **kw)
     check(m4, *m4.fit(train, val), train)
+    # ONE element edited in place, in each of the arrays a fit reads (the caches hash every
+    # byte: no edit is too small to be seen)
+    for edit in ("label", "pscore", "value", "val_label"):
+        before = _fm(pkg, **kw)
+        before.fit(train, val)
+        if edit == "label":
+            train["labels"][1501] = 1 - train["labels"][1501]
+        elif edit == "pscore":
+            train["pscores"][777] *= 0.5
+        elif edit == "value":
+            train["features"].data[train["features"].nnz // 2 + 1] += 3.0
+        else:
+            val["labels"][101] = 1 - val["labels"][101]
+        after = _fm(pkg, **kw)
+        tr_a, va_a = after.fit(train, val)
+        check(after, tr_a, va_a, train)
+        if edit != "val_label":
+            assert not np.array_equal(after.V(), before.V()), edit  # the edit changed the result
     # and with the caches switched off
     old = runtime.Runtime.remember_splits
     try:
@@ -539,6 +564,58 @@ def test_full_size_step_properties(rfm, big_log, batch, hot):
     plan.close()
 
 
+@pytest.mark.parametrize("hot", [0, -2])
+@pytest.mark.parametrize("small", [1, 300, 2000, 8000])
+def test_small_step_on_a_plan_made_for_many_rows(rfm, small, hot):
+    """A plan whose max_batch takes the many-rows forward keeps only the padded row blocks
+    (layout()['row_blocks'] == 1); the header allows any batch 1..max_batch on it, and a shard
+    of a global batch is exactly that: the small-batch forward shape must read the row blocks
+    too.  rfm_fm_step, rfm_fm_grad and rfm_fm_grad_rows against the oracle."""
+    pkg, _lib, runtime, rt = rfm
+    from relevance_factorizationmachine_amd.fm import FmPlan
+    sh = synth.SHAPES["kuairec_big"]
+    train, _ = synth.make_log(sh, "FM", "IPS", seed=0, n_train=60_000, n_val=16)
+    n, k, lr = train["features"].shape[1], 32, 1e-4
+    dev = runtime.DeviceCSR(rt, train["features"])
+    y = rt.upload(train["labels"], dtype=np.float64)
+    p = rt.upload(train["pscores"], dtype=np.float64)
+    plan = FmPlan(rt, dev, train["labels"], train["pscores"], k, 40_000, hot)
+    assert plan.layout()["row_blocks"] == 1
+    ids_h = runtime.sample_batches(dev.shape[0], small, 3, 1)[0]
+    ids = rt.upload(ids_h)
+    csr = (dev.indptr.data_ptr(), dev.indices.data_ptr(), dev.values.data_ptr(), y.data_ptr(), p.data_ptr())
+    w0, w, V = cpu_ref.fm_init(12345, n, k)
+    Xb = train["features"][ids_h]
+    err, g_w0, g_w, G_V = cpu_ref.fm_gradients(Xb, train["labels"][ids_h], train["pscores"][ids_h], w0, w, V)
+
+    m = _fm(pkg, n_factors=k, n_features=n, lr=lr, batch_size=small)
+    params = (m.w0.dev.data_ptr(), m.w.dev.data_ptr(), m.V.dev.data_ptr())
+    grad = rt.empty((n * k + n + 1,), y.dtype)
+    _lib.check(rt.lib.rfm_fm_grad(rt.ctx, plan.handle, *csr, ids.data_ptr(), small, *params, grad.data_ptr()))
+    gh = grad.cpu().numpy()
+    assert rel_err(gh[: n * k].reshape(n, k), G_V) < TIGHT
+    assert rel_err(gh[n * k: n * k + n], g_w) < TIGHT
+    assert abs(gh[-1] - g_w0) <= TIGHT * max(1.0, abs(g_w0))
+    # touched-row form
+    cap = n
+    rows = rt.empty((cap, k + 2), y.dtype)
+    n_rows = rt.empty((1,), ids.dtype)
+    gw0 = rt.empty((1,), y.dtype)
+    _lib.check(rt.lib.rfm_fm_grad_rows(rt.ctx, plan.handle, ids.data_ptr(), small, *params, rows.data_ptr(), cap,
+                                       n_rows.data_ptr(), gw0.data_ptr(), None, 0, None))
+    cnt = int(n_rows.cpu().numpy()[0])
+    rec = rows.cpu().numpy()[:cnt]
+    cols = rec[:, 0].astype(np.int64)
+    np.testing.assert_array_equal(cols, np.unique(Xb.indices))
+    assert rel_err(rec[:, 1: k + 1], G_V[cols]) < TIGHT and rel_err(rec[:, k + 1], g_w[cols]) < TIGHT
+    # the step itself
+    _lib.check(rt.lib.rfm_fm_step(rt.ctx, plan.handle, *csr, ids.data_ptr(), small, *params, lr))
+    rt.sync()
+    assert rel_err(m.V(), V - lr * G_V) < TIGHT and rel_err(m.w(), w - lr * g_w) < TIGHT
+    assert abs(m.w0(0) - (w0[0] - lr * g_w0)) <= TIGHT
+    plan.close()
+
+
 def test_full_size_forward_permutation_invariance(rfm, big_log):
     pkg, _lib, runtime, rt = rfm
     sh, train, val = big_log
@@ -784,6 +861,8 @@ def test_predict_sees_in_place_edits_of_a_cached_matrix(rfm):
     w0, w, V = cpu_ref.fm_init(12345, 30, 5)
     assert rel_err(model.predict(X), cpu_ref.fm_predict(X, w0, w, V)) < TIGHT
     X.data[:] = X.data * 2.0 + 0.25
+    assert rel_err(model.predict(X), cpu_ref.fm_predict(X, w0, w, V)) < TIGHT
+    X.data[X.nnz // 3] -= 7.0  # a single element
     assert rel_err(model.predict(X), cpu_ref.fm_predict(X, w0, w, V)) < TIGHT
 
 

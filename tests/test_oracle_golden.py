@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 from scipy.sparse import csr_matrix
 
-from conftest import load_golden, rel_err
+from conftest import assert_elementwise, load_golden, rel_err
 from oracle import cpu_ref
 from relevance_factorizationmachine_amd import synth
 
@@ -57,6 +57,9 @@ def test_fm_fit_matches_reference(fixture, shape, form, est):
     assert rel_err(out["val_loss"], g[f"{est}_val_loss"]) < TIGHT
     pred = cpu_ref.fm_predict(val["features"], out["w0"], out["w"], out["V"])
     assert rel_err(pred, g[f"{est}_pred_val"]) < TIGHT
+    for got, name in ((out["V"], "V"), (out["w"], "w"), (out["w0"], "w0"), (out["train_loss"], "train_loss"),
+                      (out["val_loss"], "val_loss"), (pred, "pred_val")):
+        assert_elementwise(got, g[f"{est}_{name}"], what=f"{fixture} {est} {name}")
 
 
 def test_fm_one_step_known_answer():

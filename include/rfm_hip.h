@@ -65,6 +65,10 @@ int32_t rfm_last_error(char* buf, size_t n);
 int32_t rfm_create(int32_t device, void* hip_stream, rfm_ctx** out);
 int32_t rfm_destroy(rfm_ctx* ctx);
 int32_t rfm_sync(rfm_ctx* ctx);
+/* Synchronous copies ordered after the work on the ctx stream (for a host-staged
+ * rfm_transport, which is handed raw device pointers). */
+int32_t rfm_copy_to_host(rfm_ctx* ctx, void* h_dst, const void* d_src, int64_t bytes);
+int32_t rfm_copy_to_device(rfm_ctx* ctx, void* d_dst, const void* h_src, int64_t bytes);
 
 /* ---- per-kernel timing (HIP events on the ctx stream) ---------------------
  * Between rfm_profile_begin and rfm_profile_end every FM training step records
@@ -176,7 +180,7 @@ int32_t rfm_fm_plan_hot_columns(const rfm_fm_plan* plan, int32_t* h_out, int32_t
  * propensity arrays are the device copy of the log the plan was built from
  * (the step reads the plan's own records of it).
  * PRECONDITION of every call that takes the row ids of a step (rfm_fm_step,
- * rfm_fm_grad, rfm_fm_grad_rows, rfm_fm_train, rfm_fm_train_dp): the ids of one
+ * rfm_fm_grad, rfm_fm_grad_rows, rfm_fm_train, rfm_fm_train_dp, rfm_fm_fit_dp): the ids of one
  * step lie in 0 .. n_rows-1 of the plan's log and are DISTINCT -- what
  * resample(replace=False) yields (src/fm.py:72-79).  A row's batch position is
  * recorded with a plain store, so a repeated id would silently lose one of its
@@ -259,6 +263,56 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
                      const double* d_val_values, const double* d_val_y,
                      const double* d_val_pscore, int64_t n_val, double eps,
                      double* d_out_train_loss, double* d_out_val_loss);
+
+/* ---- FM: the data-parallel fit() loop ------------------------
+ * The reference has no multi-process mode; this is the body of FactorizationMachines.fit
+ * (src/fm.py:71-102) for one rank of n_ranks replicas: per iteration the rank computes the
+ * batch-SUM gradient of ITS contiguous shard of the global batch d_ids[it*global_batch ..)
+ * (rank r takes rows [r*q + min(r, m), ...) with q, m = divmod(global_batch, n_ranks): the
+ * first m ranks one row more), the shards' gradients are combined, every replica applies
+ * the same update, then the train loss of the same global batch with the new parameters
+ * (src/fm.py:90-96; every rank its shard) and the validation loss (src/fm.py:98-102; the
+ * validation rows cut the same way) are formed as sums, combined over the ranks and
+ * written -- the same value on every rank -- to d_out_train_loss / d_out_val_loss
+ * (n_iters doubles each, either may be NULL).
+ *   exchange 0 (dense, what the north star names): all-reduce(sum) of [G_V | g_w | g_w0],
+ *     n_features*(n_factors+1)+1 doubles per iteration, then rfm_fm_apply.
+ *   exchange 1 (touched rows, feature-range ownership): rank r owns the columns
+ *     [n_features*r/n_ranks, n_features*(r+1)/n_ranks); per iteration the gradient records
+ *     of rfm_fm_grad_rows (+ one record for g_w0, owned by the last rank) go to the owners,
+ *     an owner adds the records of a column in RANK ORDER, updates its row and sends the
+ *     updated rows to everybody (rfm_fm_reduce_rows / rfm_fm_set_rows): each row is
+ *     computed once and copied, the replicas stay bit-identical.  Which columns a shard
+ *     touches depends on the row ids only, so the sizes of every transfer of the whole
+ *     call are derived BEFORE the loop (one count pass per iteration, one all-gather of the
+ *     counts, one host synchronisation per call); inside the loop nothing synchronises and
+ *     nothing is allocated.
+ * Transport: `transport` == NULL -> RCCL on the communicator of rfm_comm_init (n_ranks and the
+ * rank are its; no communicator = one rank, nothing is exchanged), everything on the ctx
+ * stream.  Otherwise the caller's functions move the (device) buffers -- e.g. staged through
+ * the host over another fabric, or ranks that share one GPU in a test; each must be ordered
+ * after the work already enqueued on the ctx stream and complete before it returns (or
+ * be enqueued on that stream).  Offsets and sizes are bytes; entry p of an array belongs to
+ * peer p (the rank's own entry included: a local copy).  Return 0 for success.
+ * The call ends with one synchronisation (it reads back an error flag: a transfer plan that
+ * does not match what the gradient kernels produced is RFM_ERR_INTERNAL, never a silent
+ * truncation). */
+typedef struct rfm_transport {
+  void* user;
+  int32_t n_ranks, rank;
+  int32_t (*all_gather)(void* user, const void* d_send, void* d_recv, int64_t bytes_per_rank);
+  int32_t (*all_reduce_sum)(void* user, double* d_buf, int64_t count);
+  int32_t (*all_to_all)(void* user, const void* d_send, const int64_t* h_send_off,
+                        const int64_t* h_send_bytes, void* d_recv, const int64_t* h_recv_off,
+                        const int64_t* h_recv_bytes);
+} rfm_transport;
+int32_t rfm_fm_fit_dp(rfm_ctx* ctx, rfm_fm_plan* plan, const rfm_transport* transport,
+                      int32_t exchange, const int32_t* d_ids, int64_t global_batch,
+                      int64_t n_iters, double* d_w0, double* d_w, double* d_V, double lr,
+                      const int64_t* d_val_indptr, const int32_t* d_val_indices,
+                      const double* d_val_values, const double* d_val_y,
+                      const double* d_val_pscore, int64_t n_val, double eps,
+                      double* d_out_train_loss, double* d_out_val_loss);
 
 /* ---- MF ------------------------------------------------------------------
  * Replaces LogisticMatrixFactorization.predict/_predict_pair

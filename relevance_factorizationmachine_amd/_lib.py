@@ -105,6 +105,8 @@ SIGNATURES = {
     "rfm_create": [_i32, _vp, C.POINTER(_vp)],
     "rfm_destroy": [_vp],
     "rfm_sync": [_vp],
+    "rfm_copy_to_host": [_vp, _vp, _vp, _i64],
+    "rfm_copy_to_device": [_vp, _vp, _vp, _i64],
     "rfm_profile_begin": [_vp],
     "rfm_profile_end": [_vp, _vp, _vp],
     "rfm_sample_batches": [_i64, _i64, _i64, _i64, _vp, _i32],
@@ -129,6 +131,8 @@ SIGNATURES = {
     "rfm_fm_train": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _f64,
                      _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp],
     "rfm_fm_train_dp": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f64, _vp],
+    "rfm_fm_fit_dp": [_vp, _vp, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp,
+                      _i64, _f64, _vp, _vp],
     "rfm_mf_predict": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _i32, _vp],
     "rfm_mf_predict_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _i32,
                             _f64, _vp, _vp],
@@ -153,6 +157,18 @@ SIGNATURES = {
     "rfm_topk_users": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
 }
 
+
+
+# ``rfm_transport`` of include/rfm_hip.h: the collectives of rfm_fm_fit_dp as caller functions
+TRANSPORT_ALL_GATHER = C.CFUNCTYPE(_i32, _vp, _vp, _vp, _i64)
+TRANSPORT_ALL_REDUCE = C.CFUNCTYPE(_i32, _vp, _vp, _i64)
+TRANSPORT_ALL_TO_ALL = C.CFUNCTYPE(_i32, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), _vp, C.POINTER(_i64),
+                                   C.POINTER(_i64))
+
+
+class Transport(C.Structure):
+    _fields_ = [("user", _vp), ("n_ranks", _i32), ("rank", _i32), ("all_gather", TRANSPORT_ALL_GATHER),
+                ("all_reduce_sum", TRANSPORT_ALL_REDUCE), ("all_to_all", TRANSPORT_ALL_TO_ALL)]
 
 
 class CsrSegment(C.Structure):

@@ -80,4 +80,24 @@ int32_t rfm_sync(rfm_ctx* ctx) {
   });
 }
 
+// plain copies for callers that hold raw device pointers only (a transport of rfm_fm_fit_dp
+// that stages through the host): ordered after the ctx stream's work, complete on return
+int32_t rfm_copy_to_host(rfm_ctx* ctx, void* h_dst, const void* d_src, int64_t bytes) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx && bytes >= 0 && (bytes == 0 || (h_dst && d_src)), "bad arguments");
+    if (bytes == 0) return;
+    RFM_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, size_t(bytes), hipMemcpyDeviceToHost, ctx->stream));
+    RFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int32_t rfm_copy_to_device(rfm_ctx* ctx, void* d_dst, const void* h_src, int64_t bytes) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx && bytes >= 0 && (bytes == 0 || (d_dst && h_src)), "bad arguments");
+    if (bytes == 0) return;
+    RFM_HIP_CHECK(hipMemcpyAsync(d_dst, h_src, size_t(bytes), hipMemcpyHostToDevice, ctx->stream));
+    RFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
 }  // extern "C"

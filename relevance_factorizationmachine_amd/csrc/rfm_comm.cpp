@@ -9,7 +9,8 @@
 namespace {
 
 // the handful of RCCL declarations used (rccl.h: ncclGetUniqueId, ncclCommInitRank,
-// ncclAllReduce, ncclCommDestroy, ncclGetErrorString; ncclFloat64 = 8, ncclSum = 0)
+// ncclAllReduce, ncclAllGather, ncclSend / ncclRecv inside ncclGroupStart / ncclGroupEnd,
+// ncclCommDestroy, ncclGetErrorString; ncclInt8 = 0, ncclFloat64 = 8, ncclSum = 0)
 constexpr int kNcclUniqueIdBytes = 128;
 struct UniqueId {
   char internal[kNcclUniqueIdBytes];
@@ -19,6 +20,11 @@ struct Rccl {
   int (*GetUniqueId)(UniqueId*) = nullptr;
   int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
+  int (*Send)(const void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   int (*CommDestroy)(Comm) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
@@ -48,8 +54,14 @@ const Rccl& rccl() {
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
+    a.Send = reinterpret_cast<decltype(a.Send)>(dlsym(h, "ncclSend"));
+    a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(h, "ncclRecv"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-    if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy)
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy || !a.AllGather ||
+        !a.Send || !a.Recv || !a.GroupStart || !a.GroupEnd)
       rfm::fail(RFM_ERR_INTERNAL, "librccl.so lacks an expected symbol");
     return a;
   }();
@@ -64,6 +76,58 @@ void check_rccl(int rc, const char* what) {
 }
 
 }  // namespace
+
+// the collectives of the data-parallel fit loop (rfm_fm_fit_dp) on the ctx's communicator,
+// all enqueued on the ctx stream
+namespace rfm {
+
+void comm_all_gather(rfm_ctx* ctx, const void* d_send, void* d_recv, int64_t bytes_per_rank) {
+  RFM_REQUIRE(ctx->comm, "rfm_comm_init has not been called");
+  if (bytes_per_rank <= 0) return;
+  check_rccl(rccl().AllGather(d_send, d_recv, size_t(bytes_per_rank), /*ncclInt8*/ 0, ctx->comm,
+                              ctx->stream),
+             "ncclAllGather");
+}
+
+void comm_all_reduce_sum(rfm_ctx* ctx, double* d_buf, int64_t count) {
+  RFM_REQUIRE(ctx->comm, "rfm_comm_init has not been called");
+  if (count <= 0) return;
+  check_rccl(rccl().AllReduce(d_buf, d_buf, size_t(count), /*ncclFloat64*/ 8, /*ncclSum*/ 0,
+                              ctx->comm, ctx->stream),
+             "ncclAllReduce");
+}
+
+// peer p gets d_send[send_off[p] .. + send_bytes[p]) and its block lands at d_recv + recv_off[p];
+// the rank's own block is a device copy.  xGMI is point to point: the sends and receives of
+// one exchange are fused in one group so that all links carry traffic at once.
+void comm_all_to_all(rfm_ctx* ctx, int rank, const void* d_send, const int64_t* send_off,
+                     const int64_t* send_bytes, void* d_recv, const int64_t* recv_off,
+                     const int64_t* recv_bytes) {
+  RFM_REQUIRE(ctx->comm, "rfm_comm_init has not been called");
+  const Rccl& a = rccl();
+  const char* src = static_cast<const char*>(d_send);
+  char* dst = static_cast<char*>(d_recv);
+  RFM_REQUIRE(send_bytes[rank] == recv_bytes[rank], "own block: %lld bytes sent, %lld expected",
+              (long long)send_bytes[rank], (long long)recv_bytes[rank]);
+  if (send_bytes[rank] > 0 && src + send_off[rank] != dst + recv_off[rank])
+    RFM_HIP_CHECK(hipMemcpyAsync(dst + recv_off[rank], src + send_off[rank], size_t(send_bytes[rank]),
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+  bool any = false;
+  for (int p = 0; p < ctx->comm_ranks; ++p)
+    any = any || (p != rank && (send_bytes[p] > 0 || recv_bytes[p] > 0));
+  if (!any) return;
+  check_rccl(a.GroupStart(), "ncclGroupStart");
+  for (int p = 0; p < ctx->comm_ranks; ++p) {
+    if (p == rank) continue;
+    if (send_bytes[p] > 0)
+      check_rccl(a.Send(src + send_off[p], size_t(send_bytes[p]), 0, p, ctx->comm, ctx->stream), "ncclSend");
+    if (recv_bytes[p] > 0)
+      check_rccl(a.Recv(dst + recv_off[p], size_t(recv_bytes[p]), 0, p, ctx->comm, ctx->stream), "ncclRecv");
+  }
+  check_rccl(a.GroupEnd(), "ncclGroupEnd");
+}
+
+}  // namespace rfm
 
 using namespace rfm;
 
@@ -90,6 +154,7 @@ int32_t rfm_comm_init(rfm_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t
     check_rccl(rccl().CommInitRank(&comm, n_ranks, id, rank), "ncclCommInitRank");
     ctx->comm = comm;
     ctx->comm_ranks = n_ranks;
+    ctx->comm_rank = rank;
   });
 }
 

@@ -110,6 +110,9 @@ inline Shape shape_for(int k) {
   s.lpr = lpr;
   int nc = 1;
   while (lpr * nc < units) nc *= 2;
+  // three chunks where they cover the row (k = 258 .. 384: the reference's Coat runs use 300):
+  // a fourth would be loaded and masked
+  if (nc == 4 && lpr * 3 >= units) nc = 3;
   s.nc = nc;
   return s;
 }
@@ -127,6 +130,7 @@ inline Shape shape_for(int k) {
           default: CALL(64, 2, 1); break;                                              \
         }                                                                              \
       } else if (_s.nc == 2) { CALL(64, 2, 2); }                                       \
+      else if (_s.nc == 3) { CALL(64, 2, 3); }                                         \
       else if (_s.nc == 4) { CALL(64, 2, 4); }                                         \
       else { CALL(64, 2, 8); }                                                         \
     } else {                                                                           \
@@ -139,12 +143,47 @@ inline Shape shape_for(int k) {
           default: CALL(64, 1, 1); break;                                              \
         }                                                                              \
       } else if (_s.nc == 2) { CALL(64, 1, 2); }                                       \
+      else if (_s.nc == 3) { CALL(64, 1, 3); }                                         \
       else if (_s.nc == 4) { CALL(64, 1, 4); }                                         \
       else if (_s.nc == 8) { CALL(64, 1, 8); }                                         \
       else { CALL(64, 1, 16); }                                                        \
     }                                                                                  \
   } while (0)
 
+// the single-chunk shapes only (callers that handle several chunks per lane another way)
+#define RFM_FOR_SINGLE_CHUNK_SHAPE(S, CALL)                                            \
+  do {                                                                                 \
+    const ::rfm::Shape _s = (S);                                                       \
+    if (_s.nc != 1) ::rfm::fail(RFM_ERR_INTERNAL, "single-chunk dispatch of nc=%d", _s.nc); \
+    if (_s.vec == 2) {                                                                 \
+      switch (_s.lpr) {                                                                \
+        case 4: CALL(4, 2, 1); break;                                                  \
+        case 8: CALL(8, 2, 1); break;                                                  \
+        case 16: CALL(16, 2, 1); break;                                                \
+        case 32: CALL(32, 2, 1); break;                                                \
+        default: CALL(64, 2, 1); break;                                                \
+      }                                                                                \
+    } else {                                                                           \
+      switch (_s.lpr) {                                                                \
+        case 4: CALL(4, 1, 1); break;                                                  \
+        case 8: CALL(8, 1, 1); break;                                                  \
+        case 16: CALL(16, 1, 1); break;                                                \
+        case 32: CALL(32, 1, 1); break;                                                \
+        default: CALL(64, 1, 1); break;                                                \
+      }                                                                                \
+    }                                                                                  \
+  } while (0)
+
+}  // namespace rfm
+
+struct rfm_ctx;
+namespace rfm {
+// RCCL collectives on the ctx's communicator and stream (rfm_comm.cpp)
+void comm_all_gather(rfm_ctx* ctx, const void* d_send, void* d_recv, int64_t bytes_per_rank);
+void comm_all_reduce_sum(rfm_ctx* ctx, double* d_buf, int64_t count);
+void comm_all_to_all(rfm_ctx* ctx, int rank, const void* d_send, const int64_t* send_off,
+                     const int64_t* send_bytes, void* d_recv, const int64_t* recv_off,
+                     const int64_t* recv_bytes);
 }  // namespace rfm
 
 struct rfm_ctx {
@@ -154,6 +193,7 @@ struct rfm_ctx {
   rfm::DevBuf loss_partials;  // per-block partial sums of the loss reduction
   void* comm = nullptr;       // RCCL communicator (rfm_comm_init), or null
   int32_t comm_ranks = 0;
+  int32_t comm_rank = 0;
   // per-kernel timing (rfm_profile_begin/end): 4 events per recorded step
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;

@@ -250,7 +250,14 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   f.out_err = plan->err.as<double>();
   f.out_Q = plan->Q.as<double>();
   f.slot_mark = plan->slot_t.as<SlotMark>();
-  f.slot_bits = plan->slot_bits.as<unsigned long long>();
+  // more than one chunk per lane: the slot bitmap alternates between two buffers by step
+  // parity (see fm_consume_kernel, CH form)
+  const bool chunked = s.nc > 1;
+  const int64_t parity = chunked ? ((plan->step + 1) & 1) : 0;
+  unsigned long long* bits = plan->slot_bits.as<unsigned long long>() + parity * plan->bits_words;
+  unsigned long long* bits_other =
+      plan->slot_bits.as<unsigned long long>() + (1 - parity) * plan->bits_words;
+  f.slot_bits = bits;
   f.n_hot = plan->n_hot;
   f.hot_rounds = plan->hot_rounds;
   f.hot_fixed = plan->hot_fixed ? 1 : 0;
@@ -276,7 +283,8 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
     ConsArgs c{};
     c.tasks = plan->tasks.as<TaskRec>();
     c.task_words = plan->task_words;
-    c.slot_bits = plan->slot_bits.as<unsigned long long>();
+    c.slot_bits = bits;
+    c.slot_bits_other = bits_other;
     c.slot_mark = plan->slot_t.as<SlotMark>();
     c.slots = plan->slots.as<SlotRec>();
     c.Q = plan->Q.as<double>();
@@ -308,10 +316,21 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
     if (!(f.ablate & 128))
 #endif
     {
+      if (chunked) {
+        // one workgroup per (four tasks, chunk of 64 lanes x vec factors)
+        const int n_chunks = ((k + s.vec - 1) / s.vec + 63) / 64;
+        if (s.vec == 2)
+          hipLaunchKernelGGL((fm_consume_kernel<64, 2, 1, true>), dim3(grid, n_chunks), dim3(kBlock),
+                             lds, ctx->stream, c);
+        else
+          hipLaunchKernelGGL((fm_consume_kernel<64, 1, 1, true>), dim3(grid, n_chunks), dim3(kBlock),
+                             lds, ctx->stream, c);
+      } else {
 #define RFM_CALL_CONS(L, Vv, N) \
   hipLaunchKernelGGL((fm_consume_kernel<L, Vv, N>), dim3(grid), dim3(kBlock), lds, ctx->stream, c)
-      RFM_FOR_SHAPE(s, RFM_CALL_CONS);
+        RFM_FOR_SINGLE_CHUNK_SHAPE(s, RFM_CALL_CONS);
 #undef RFM_CALL_CONS
+      }
       RFM_HIP_CHECK(hipGetLastError());
     }
   }
@@ -426,6 +445,8 @@ FwdArgs forward_args(const int64_t* d_indptr, const int32_t* d_indices, const do
 }
 
 }  // namespace
+
+#include "rfm_fm_dp.hpp"
 
 extern "C" {
 
@@ -542,45 +563,10 @@ int32_t rfm_fm_grad_rows(rfm_ctx* ctx, rfm_fm_plan* plan, const int32_t* d_row_i
     RFM_REQUIRE(n_ranges >= 0 && n_ranges <= kMaxRanges, "n_ranges=%d outside 0..%d", n_ranges,
                 kMaxRanges);
     RFM_REQUIRE(n_ranges == 0 || (d_range_lo && d_range_bounds), "null range arrays");
-    const int64_t n = plan->n_features;
-    const int k = plan->k;
-    if (!plan->row_table.p) {
-      plan->row_table.alloc((size_t(n) * size_t(k + 1) + 1) * sizeof(double));
-      plan->touch.alloc(size_t(n) * 4);
-      plan->chunk_cnt.alloc(size_t((n + kTouchChunk - 1) / kTouchChunk) * 4);
-      plan->touch_seq = 0;
-    }
-    if (plan->touch_seq == 0 || plan->touch_seq == INT32_MAX) {
-      RFM_HIP_CHECK(hipMemsetAsync(plan->touch.p, 0, plan->touch.bytes, ctx->stream));
-      plan->touch_seq = 0;
-    }
-    const int32_t id = ++plan->touch_seq;
-    double* table = plan->row_table.as<double>();
-    int32_t* touch = plan->touch.as<int32_t>();
+    const int32_t id = next_touch_ids(ctx, plan, 1);
     validate_ids(ctx, plan, d_row_ids, batch, 1);
-    if (batch > 0) {
-      enqueue_step(ctx, plan, nullptr, nullptr, nullptr, nullptr, nullptr, d_row_ids, batch,
-                   const_cast<double*>(d_w0), const_cast<double*>(d_w), const_cast<double*>(d_V),
-                   0.0, table, touch, id);
-    } else {  // an empty shard touches nothing
-      RFM_HIP_CHECK(hipMemsetAsync(table + n * (k + 1), 0, sizeof(double), ctx->stream));
-    }
-    const int n_chunks = int((n + kTouchChunk - 1) / kTouchChunk);
-    int32_t* chunk = plan->chunk_cnt.as<int32_t>();
-    hipLaunchKernelGGL(touch_count_kernel, dim3(n_chunks), dim3(kBlock), 0, ctx->stream, touch, id,
-                       n, chunk);
-    hipLaunchKernelGGL(touch_list_kernel, dim3(n_chunks), dim3(kBlock), 0, ctx->stream, touch, id,
-                       n, k, chunk, n_chunks, table, d_rows, cap_rows, d_n_rows, d_gw0,
-                       n_ranges ? d_range_lo : nullptr, int(n_ranges), d_range_bounds);
-    {
-      const int wpb = kBlock / kWave;
-      const int64_t most = std::min<int64_t>(cap_rows, n);
-      const int grid = int(std::max<int64_t>(
-          1, std::min<int64_t>((most + wpb - 1) / wpb, int64_t(ctx->n_cu) * 8)));
-      hipLaunchKernelGGL(rows_fill_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, table, d_rows,
-                         d_n_rows, cap_rows, n, k);
-    }
-    RFM_HIP_CHECK(hipGetLastError());
+    enqueue_grad_rows(ctx, plan, id, d_row_ids, batch, d_w0, d_w, d_V, d_rows, cap_rows, d_n_rows,
+                      d_gw0, d_range_lo, n_ranges, d_range_bounds);
   });
 }
 

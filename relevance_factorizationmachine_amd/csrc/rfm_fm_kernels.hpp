@@ -782,6 +782,7 @@ struct ConsArgs {
   const TaskRec* tasks;  // [nb_tasks * tasks per workgroup]
   int32_t task_words;    // 64-slot words of the slot bitmap per task
   unsigned long long* slot_bits;  // one bit per slot: set by the forward, cleared here
+  unsigned long long* slot_bits_other;  // CH form: the bitmap of the step before, cleared here
   const SlotMark* slot_mark;      // {batch position, residual} of a marked slot's row
   const SlotRec* slots;
   const double* Q;
@@ -822,14 +823,16 @@ struct ColAcc {
 
 // V[col,:] and w[col] from the sums of one column: update in place, or write the
 // gradient row (grad mode).  vold = the row as it was read before.
+// (fb: first factor of the chunk this lane group works on -- 0 unless the chunks of a row are
+// dealt to different workgroups; the scalar part, w / touch, is then written by chunk 0)
 template <int LPR, int VEC, int NC>
 __device__ inline void apply_column(const ColAcc<VEC, NC>& acc, const Pack<VEC> (&vold)[NC],
                                     int32_t col, double* V, double* w, double* grad, int64_t n,
                                     int k, double lr, int l, int32_t* touch = nullptr,
-                                    int32_t touch_id = 0) {
+                                    int32_t touch_id = 0, int fb = 0) {
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    const int f = (c * LPR + l) * VEC;
+    const int f = fb + (c * LPR + l) * VEC;
     if (f < k) {
       Pack<VEC> out;
       if (grad) {
@@ -844,7 +847,7 @@ __device__ inline void apply_column(const ColAcc<VEC, NC>& acc, const Pack<VEC> 
       }
     }
   }
-  if (l == 0) {
+  if (l == 0 && fb == 0) {
     if (grad) {
       grad[n * k + col] = -acc.gw;
       if (touch) touch[col] = touch_id;  // touched-row mode: the row is valid for this step
@@ -913,12 +916,26 @@ __device__ inline int group_scan(int v, int l) {
 // launch follows the batch (marked slots): an untouched task reads its bitmap words and
 // waits at the barrier.
 // (The lane groups of a wave run in lock step: ballots and shuffles are wave-wide.)
-template <int LPR, int VEC, int NC>
+#ifndef RFM_CONS_CH_BATCH
+#define RFM_CONS_CH_BATCH 4
+#endif
+// CH (factor counts of more than one chunk per lane): the chunks of a row are dealt to
+// DIFFERENT workgroups -- blockIdx.y = chunk, LPR x VEC factors each, NC = 1 in registers -- so
+// that a task's chain is one 16-byte load per lane and entry instead of NC of them, NC times as
+// many lane groups share the step's entries (measured at k = 400, B = 2 000: equal to the
+// all-chunks-in-registers form within noise -- both wait on the same chain of dependent levels --
+// at half the registers and with one instantiation for every chunk count).  Every
+// chunk lists the task's marks itself (same bitmap words: they hit in L2), so the words cannot be
+// cleared while a sibling may still read them: the bitmap is double-buffered by step parity and
+// chunk 0 clears the task's words of the OTHER buffer (the step before, long consumed).
+template <int LPR, int VEC, int NC, bool CH = false>
 __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
+  static_assert(!CH || NC == 1, "the chunked form holds one chunk per lane group");
   constexpr int GPB = kBlock / LPR;  // tasks of a workgroup
   constexpr int PLANES = WinShape<LPR>::PLANES;
   constexpr int WIN = WinShape<LPR>::WIN;  // marked slots a group lists before it runs the chain
-  constexpr int BATCH = 4;                 // entries whose Q and V rows are in flight together
+  constexpr int BATCH = CH ? RFM_CONS_CH_BATCH : 4;  // entries whose Q and V rows are in flight together
+  const int fb = CH ? int(blockIdx.y) * (LPR * VEC) : 0;  // first factor of this workgroup's chunk
   constexpr int TRIPS = kTaskTrips;        // bitmap words a lane loads (task_words <= TRIPS*LPR)
   // LDS: per group the list of marked slots and their parked records, then the head rows; or
   // (hot-column / w0 workgroups) reduction scratch
@@ -929,6 +946,7 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
   // the hot-column workgroups come last in the grid (measured: first, they delay the
   // tasks and the launch takes longer)
   if (int(blockIdx.x) >= a.nb_tasks) {
+    if (CH && blockIdx.y != 0) return;
     const int hb = int(blockIdx.x) - a.nb_tasks;
     double* tot = lds_raw + kBlock;
     if (hb < a.n_hot) {
@@ -967,8 +985,13 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
   }
   const TaskRec tk = a.tasks[task];
 #pragma unroll
-  for (int u = 0; u < TRIPS; ++u)
-    if (wd[u]) a.slot_bits[int64_t(task) * W + u * LPR + l] = 0ull;  // consumed: cleared at once
+  for (int u = 0; u < TRIPS; ++u) {
+    if (CH) {
+      if (fb == 0 && u * LPR + l < W) a.slot_bits_other[int64_t(task) * W + u * LPR + l] = 0ull;
+    } else if (wd[u]) {
+      a.slot_bits[int64_t(task) * W + u * LPR + l] = 0ull;  // consumed: cleared at once
+    }
+  }
 
   char* gmem = reinterpret_cast<char*>(lds_raw) + gb * kGroupBytes;
   WinRec* wrec = reinterpret_cast<WinRec*>(gmem);
@@ -991,7 +1014,7 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
     if (head_open && cur == tk.first_col) {
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const int f = (c * LPR + l) * VEC;
+        const int f = fb + (c * LPR + l) * VEC;
         if (f < k) {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) head[f + v] = acc.m[c][v];
@@ -1004,7 +1027,7 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
       head_done = true;
     } else {
       apply_column<LPR, VEC, NC>(acc, vold, cur, a.V, a.w, a.grad, a.n, k, a.lr, l, a.touch,
-                                 a.touch_id);
+                                 a.touch_id, fb);
     }
   };
 
@@ -1048,14 +1071,14 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
         // items in a small batch) costs one round trip, not one per column
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch) {
-          const int f = (ch * LPR + l) * VEC;
+          const int f = fb + (ch * LPR + l) * VEC;
           qq[u][ch].load(a.Q + int64_t(rec[u].t) * k + (f < k ? f : 0));
         }
         // (an entry of the column the one before it belongs to needs no V row)
         if (rec[u].col != (u == 0 ? cur : rec[u > 0 ? u - 1 : 0].col)) {
 #pragma unroll
           for (int ch = 0; ch < NC; ++ch) {
-            const int f = (ch * LPR + l) * VEC;
+            const int f = fb + (ch * LPR + l) * VEC;
             vv[u][ch].load(a.V + int64_t(rec[u].col) * k + (f < k ? f : 0));
           }
         }
@@ -1131,7 +1154,7 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
       acc.clear();
 #pragma unroll
       for (int ch = 0; ch < NC; ++ch) {
-        const int f = (ch * LPR + l) * VEC;
+        const int f = fb + (ch * LPR + l) * VEC;
         vold[ch].load(a.V + int64_t(tk.last_col) * k + (f < k ? f : 0));
       }
     }
@@ -1143,7 +1166,7 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
         any = true;
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch) {
-          const int f = (ch * LPR + l) * VEC;
+          const int f = fb + (ch * LPR + l) * VEC;
           if (f < k) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc.m[ch][v] += h2[f + v];
@@ -1159,20 +1182,20 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
       double* row = a.parts + int64_t(tk.part) * (k + 3);
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const int f = (c * LPR + l) * VEC;
+        const int f = fb + (c * LPR + l) * VEC;
         if (f < k) {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) row[f + v] = acc.m[c][v];
         }
       }
-      if (l == 0) {
+      if (l == 0 && fb == 0) {
         row[k] = acc.gw;
         row[k + 1] = acc.d;
         row[k + 2] = any ? a.stamp : 0.0;
       }
     } else if (any) {
       apply_column<LPR, VEC, NC>(acc, vold, tk.last_col, a.V, a.w, a.grad, a.n, k, a.lr, l,
-                                 a.touch, a.touch_id);
+                                 a.touch, a.touch_id, fb);
     }
   }
 }

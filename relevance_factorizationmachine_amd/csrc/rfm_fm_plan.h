@@ -17,6 +17,7 @@ struct rfm_fm_plan {
   int32_t hot_rounds = 1;  // rounds of a lane group's entries that cover the longest row
   bool hot_fixed = false;  // hot-class sums in a fixed order (hot_min_count = -2)
   int64_t step = 0;  // stamps the partial rows of a step
+  int64_t bits_words = 0;  // 64-slot words of ONE slot bitmap (slot_bits holds two)
   int32_t fwd_grid_max = 0;  // forward workgroups of a max_batch step (= hot-sum slabs)
   rfm::DevBuf ell;            // padded row blocks (every row <= lanes-per-group entries), else empty
   rfm::DevBuf ell_yp;         // ... with the rows' {label, propensity} pairs
@@ -30,6 +31,10 @@ struct rfm_fm_plan {
   // rows of the current step
   rfm::DevBuf row_table, touch, chunk_cnt;
   int32_t touch_seq = 0;
+  // rfm_fm_fit_dp (grown on demand, kept between calls): dense gradient, loss sums, record
+  // lists (mine / received / everybody's updated rows), transfer-plan arrays, small scratch
+  rfm::DevBuf dp_grad, dp_sums, dp_rows, dp_recv, dp_all, dp_bounds, dp_all_bounds, dp_seg,
+      dp_range_lo, dp_small;
   rfm::DevBuf ids_seen, ids_flags;  // RFM_CHECK_IDS=1: validation of the steps' row ids
   int32_t ids_stamp = 0;
   size_t device_bytes() const {

@@ -220,7 +220,14 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
   // the forward shapes this plan can take are built for them; otherwise as -1 (no hot class)
   const bool fixed = hot_min_count == -2 && forward_fixed_order_ok(ctx, max_batch, n_factors) &&
                      env_int("RFM_NO_FIXED_HOT", 0) == 0;
-  if (hot_min_count >= 0 || fixed) {
+  // Factor counts of more than one chunk per lane (k > 128, or odd k > 64) have NO on-chip
+  // class: a column's LDS sums are k + 2 doubles (17 columns fit at k = 400) and every forward
+  // workgroup -- four rows each at that width -- would leave a slab of them; measured at the
+  // reference's published point (k = 400, B = 2 000; profiles/r3b): 76 us per step with the
+  // class, 52 us without.  All sums then have a fixed order: such fits are bitwise
+  // reproducible whatever hot_min_count says.  (RFM_HOT_MULTI_CHUNK=1: the old behaviour.)
+  const bool chunked = shape_for(n_factors).nc > 1 && env_int("RFM_HOT_MULTI_CHUNK", 0) == 0;
+  if ((hot_min_count >= 0 || fixed) && !chunked) {
     const int64_t hot_min = hot_min_count > 0 ? hot_min_count : kDefaultHotMinCount;
     for (size_t c = 0; c < nf; ++c)
       if (len(c) * max_batch >= hot_min * n_rows) hot_cols.push_back(int32_t(c));
@@ -245,7 +252,10 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
   const int64_t GPB = kBlock / shp.lpr;
   const double density = double(max_batch) / double(n_rows);  // marked fraction of a column
   int64_t W = 1;
-  while (W * 2 * 64 * density <= 1.5 * kTaskMarks && W * 2 <= int64_t(kTaskTrips) * shp.lpr) W *= 2;
+  // (several chunks per lane: twice the marks per task -- measured at k = 400, B = 2 000:
+  // 81 / 51 / 49 / 55 us per step at 2 / 4 / 8 / 16 words, profiles/r3c)
+  const int task_marks = shp.nc > 1 ? 2 * kTaskMarks : kTaskMarks;
+  while (W * 2 * 64 * density <= 1.5 * task_marks && W * 2 <= int64_t(kTaskTrips) * shp.lpr) W *= 2;
   if (const int forced = env_int("RFM_TASK_WORDS", 0))  // tuning experiments only
     W = std::max<int64_t>(1, std::min<int64_t>(forced, int64_t(kTaskTrips) * shp.lpr));
   const int64_t C = W * 64;     // slots of a task
@@ -362,7 +372,10 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
   upload(plan->hot_cols, hot_cols.data(), hot_cols.size() * 4, st);
   plan->slot_t.alloc((ns + 256) * sizeof(SlotMark));
   RFM_HIP_CHECK(hipMemsetAsync(plan->slot_t.p, 0, plan->slot_t.bytes, st));
-  plan->slot_bits.alloc((ns / 64 + 8) * 8);
+  // (two bitmaps, used by alternate steps: the chunked form of fm_consume_kernel clears the
+  // other step's; the single-chunk form only ever uses the first)
+  plan->bits_words = int64_t(ns / 64 + 8);
+  plan->slot_bits.alloc(size_t(plan->bits_words) * 2 * 8);
   RFM_HIP_CHECK(hipMemsetAsync(plan->slot_bits.p, 0, plan->slot_bits.bytes, st));
   // partial rows [n_parts][k+3]; stamp 0 never matches a step id (they start at 1)
   plan->parts.alloc(std::max<size_t>(size_t(n_parts), 1) * size_t(n_factors + 3) * 8);

@@ -151,11 +151,14 @@ __global__ __launch_bounds__(kBlock) void rows_apply_kernel(const double* rows, 
 // updates the owner's row and emits [column, V_new, w_new] at its own position; every
 // other record's position gets column -1 (so positions, and the list size, are known
 // before the kernel runs).
+// (w0 given: a record with column == n carries a rank's g_w0 in its g_w field; it is reduced
+// like any other -- rank order -- and emitted as [n, 0.., w0_new])
 __global__ __launch_bounds__(kBlock) void rows_reduce_kernel(const double* rows,
                                                             const int32_t* seg_ptr, int n_seg,
                                                             const double* w, const double* V,
                                                             int64_t n, int k, double lr,
-                                                            double* out_rows) {
+                                                            double* out_rows,
+                                                            const double* w0 = nullptr) {
   const int lane = threadIdx.x % kWave;
   const int64_t wave = int64_t(blockIdx.x) * (kBlock / kWave) + threadIdx.x / kWave;
   const int64_t n_waves = int64_t(gridDim.x) * (kBlock / kWave);
@@ -186,7 +189,8 @@ __global__ __launch_bounds__(kBlock) void rows_reduce_kernel(const double* rows,
     }
     const unsigned long long has = __ballot(at >= 0);
     const int my_seg = __ffsll((long long)__ballot(own >= 0)) - 1;
-    const bool leader = (has & ((1ull << my_seg) - 1ull)) == 0ull && col >= 0 && col < n;
+    const bool is_w0 = w0 != nullptr && col == n;
+    const bool leader = (has & ((1ull << my_seg) - 1ull)) == 0ull && col >= 0 && (col < n || is_w0);
     double* out = out_rows + i * width;
     if (!leader) {
       if (lane == 0) out[0] = -1.0;
@@ -200,20 +204,21 @@ __global__ __launch_bounds__(kBlock) void rows_reduce_kernel(const double* rows,
         if (j >= 0 && f <= k) sum += rows[j * width + 1 + f];
       }
       if (f < k)
-        out[1 + f] = V[col * k + f] - lr * sum;
+        out[1 + f] = is_w0 ? 0.0 : V[col * k + f] - lr * sum;
       else if (f == k)
-        out[1 + k] = w[col] - lr * sum;
+        out[1 + k] = (is_w0 ? w0[0] : w[col]) - lr * sum;
     }
     if (lane == 0) out[0] = colf;
   }
 }
 
 // store updated rows into a replica; w0 -= lr * (sum of the ranks' partial g_w0, in rank order)
+// (w0_records: a record with column == n holds the new w0 in its w field)
 __global__ __launch_bounds__(kBlock) void rows_set_kernel(const double* rows, int64_t n_rows,
                                                          const double* gw0_parts, int n_parts,
                                                          int64_t part_stride, double* w0,
                                                          double* w, double* V, int64_t n, int k,
-                                                         double lr) {
+                                                         double lr, bool w0_records = false) {
   const int lane = threadIdx.x % kWave;
   const int64_t wave = int64_t(blockIdx.x) * (kBlock / kWave) + threadIdx.x / kWave;
   const int64_t n_waves = int64_t(gridDim.x) * (kBlock / kWave);
@@ -221,6 +226,10 @@ __global__ __launch_bounds__(kBlock) void rows_set_kernel(const double* rows, in
   for (int64_t i = wave; i < n_rows; i += n_waves) {
     const double* row = rows + i * width;
     const int64_t col = int64_t(row[0]);
+    if (w0_records && col == n) {
+      if (lane == 0) w0[0] = row[k + 1];
+      continue;
+    }
     if (col < 0 || col >= n) continue;
     for (int f = lane; f < k; f += kWave) V[col * k + f] = row[1 + f];
     if (lane == 0) w[col] = row[k + 1];
@@ -230,6 +239,74 @@ __global__ __launch_bounds__(kBlock) void rows_set_kernel(const double* rows, in
     for (int r = 0; r < n_parts; ++r) s += gw0_parts[r * part_stride];
     w0[0] -= lr * s;
   }
+}
+
+// ---------------------------------------------------------------------------
+// the data-parallel fit loop (rfm_fm_fit_dp): transfer sizes ahead of the loop
+// ---------------------------------------------------------------------------
+// Which columns a shard's gradient records name depends on the row ids alone: the columns of
+// the shard's entries, plus -- when the shard is not empty -- every on-chip (hot) column of the
+// plan (their workgroups always write a row).  One thread per (row, entry position): stamps
+// touch[column] = id, exactly what the gradient kernels will stamp.
+__global__ __launch_bounds__(kBlock) void rows_mark_kernel(const Entry* ent, const RowRec* rows,
+                                                          const char* ell, int64_t ell_stride,
+                                                          int lpr, const int32_t* row_ids,
+                                                          int64_t n_rows, int32_t* touch,
+                                                          int32_t id, const int32_t* hot_cols,
+                                                          int n_hot) {
+  const int64_t tid = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  if (ell) {
+    for (int64_t i = tid; i < n_rows * lpr; i += stride) {
+      const Entry e = reinterpret_cast<const Entry*>(ell + int64_t(row_ids[i / lpr]) * ell_stride)[i % lpr];
+      if (e.slot != kNilSlot) touch[e.col] = id;
+    }
+  } else {
+    // a wave per row: rows of the plain records can be of any length
+    const int lane = threadIdx.x % kWave;
+    for (int64_t t = tid / kWave; t < n_rows; t += stride / kWave) {
+      const RowRec rec = rows[row_ids[t]];
+      for (int64_t j = lane; j < rec.len; j += kWave) touch[ent[rec.begin + j].col] = id;
+    }
+  }
+  if (n_rows > 0)
+    for (int64_t h = tid; h < n_hot; h += stride) touch[hot_cols[h]] = id;
+}
+
+// appends the record that carries the shard's g_w0: [n, 0.., g_w0] at position *n_rows
+__global__ void rows_append_w0_kernel(double* rows, const int32_t* n_rows, int64_t cap_rows,
+                                      const double* gw0, int64_t n, int k) {
+  const int64_t at = n_rows[0];
+  if (at >= cap_rows) return;  // (the bounds check below reports the overflow)
+  double* row = rows + at * (k + 2);
+  for (int f = threadIdx.x; f < k + 2; f += blockDim.x)
+    row[f] = f == 0 ? double(n) : (f == k + 1 ? gw0[0] : 0.0);
+}
+
+// the record list a step produced must be what the count pass promised: range bounds equal
+// (the last one + 1 for the g_w0 record) and within capacity; otherwise flag[0] = iteration + 1
+__global__ void bounds_check_kernel(const int32_t* actual, const int32_t* planned, int n_ranges,
+                                    int64_t cap_rows, int32_t it, int32_t* flag) {
+  const int i = threadIdx.x;
+  if (i > n_ranges) return;
+  const int32_t want = planned[i] - (i == n_ranges ? 1 : 0);
+  if (actual[i] != want || planned[n_ranges] > cap_rows) atomicCAS(&flag[0], 0, it + 1);
+}
+
+// raw sums of the per-workgroup loss partials of a run of launches (block b: launch b), and
+// their scaling once the ranks' sums have been combined: out = -sum / n_rows
+__global__ __launch_bounds__(kBlock) void loss_sum_many_kernel(const double* partial, int64_t stride,
+                                                              int n_partial, double* out) {
+  __shared__ double lds[kBlock];
+  const double* row = partial + int64_t(blockIdx.x) * stride;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_partial; i += kBlock) acc += row[i];
+  const double s = block_sum<kBlock>(acc, lds);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+__global__ void loss_scale_kernel(const double* sums, int64_t count, double n_rows, double* out) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = -sums[i] / n_rows;
 }
 
 }  // namespace rfm

@@ -606,8 +606,15 @@ def test_small_step_on_a_plan_made_for_many_rows(rfm, small, hot):
     cnt = int(n_rows.cpu().numpy()[0])
     rec = rows.cpu().numpy()[:cnt]
     cols = rec[:, 0].astype(np.int64)
-    np.testing.assert_array_equal(cols, np.unique(Xb.indices))
+    # ascending, every touched column present; the on-chip (hot) columns are always listed,
+    # with a zero gradient when no row of the batch holds them
+    assert np.all(np.diff(cols) > 0)
+    touched = np.unique(Xb.indices)
+    assert np.isin(touched, cols).all()
+    extra = np.setdiff1d(cols, touched)
+    assert np.isin(extra, plan.hot_columns()).all()
     assert rel_err(rec[:, 1: k + 1], G_V[cols]) < TIGHT and rel_err(rec[:, k + 1], g_w[cols]) < TIGHT
+    assert np.all(rec[np.isin(cols, extra), 1:] == 0.0)
     # the step itself
     _lib.check(rt.lib.rfm_fm_step(rt.ctx, plan.handle, *csr, ids.data_ptr(), small, *params, lr))
     rt.sync()

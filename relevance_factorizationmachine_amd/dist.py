@@ -450,3 +450,251 @@ def hip_mf_partition_worker(rt, model, train: dict, world: int, rank: int, all_r
         rt.sync()
 
     return step, finish
+
+
+# ---------------------------------------------------------------------------
+# data-parallel fit(): the reference's loop (src/fm.py:71-112) on several GPUs
+# ---------------------------------------------------------------------------
+class HostStagedTransport:
+    """The three collectives of ``rfm_fm_fit_dp`` over ``torch.distributed`` with the payloads
+    staged through host memory: the transport of the gloo rehearsals and of ranks that share
+    one GPU in the tests.  (With backend nccl nothing of this is used: ``transport=None`` makes
+    the library call RCCL itself, on the compute stream -- ``init_direct_rccl``.)
+
+    Host API (NumPy in, NumPy out) for engines that keep their buffers on the host; ``c_struct``
+    wraps it as the ``rfm_transport`` of include/rfm_hip.h for the HIP engine, which hands the
+    callbacks raw device pointers (``rfm_copy_to_host`` / ``rfm_copy_to_device``)."""
+
+    def __init__(self, world: int, rank: int, rt=None, group=None):
+        import torch.distributed as dist
+
+        self.dist, self.world, self.rank, self.rt, self.group = dist, world, rank, rt, group
+        self.error = None
+        self._keep = None
+
+    # ---- host API ---------------------------------------------------------
+    def all_gather_host(self, arr):
+        import numpy as np
+        import torch
+
+        mine = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1))
+        out = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine, group=self.group)
+        return np.stack([o.numpy() for o in out]).view(arr.dtype).reshape((self.world,) + tuple(arr.shape))
+
+    def all_reduce_sum_host(self, arr):
+        import numpy as np
+        import torch
+
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64).copy())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.numpy()
+
+    def all_to_all_host(self, send, recv_bytes):
+        """``send[p]``: uint8 array for peer p; returns the list of uint8 arrays received
+        (``recv_bytes[p]`` bytes from peer p)."""
+        import numpy as np
+        import torch
+
+        src = torch.from_numpy(np.concatenate([np.ascontiguousarray(s).view(np.uint8).reshape(-1) for s in send])
+                               if sum(len(s) for s in send) else np.zeros(0, np.uint8))
+        out = torch.empty(int(sum(recv_bytes)), dtype=torch.uint8)
+        self.dist.all_to_all_single(out, src, [int(b) for b in recv_bytes], [int(len(s)) for s in send],
+                                    group=self.group)
+        got, at = [], 0
+        for b in recv_bytes:
+            got.append(out.numpy()[at:at + int(b)])
+            at += int(b)
+        return got
+
+    # ---- the C struct -----------------------------------------------------
+    def c_struct(self):
+        import ctypes as C
+
+        import numpy as np
+
+        from . import _lib
+
+        rt, W = self.rt, self.world
+        assert rt is not None, "a transport for the HIP engine needs the runtime"
+
+        def d2h(ptr, nbytes):
+            buf = np.empty(int(nbytes), dtype=np.uint8)
+            _lib.check(rt.lib.rfm_copy_to_host(rt.ctx, buf.ctypes.data, ptr, int(nbytes)))
+            return buf
+
+        def h2d(ptr, buf):
+            buf = np.ascontiguousarray(buf)
+            _lib.check(rt.lib.rfm_copy_to_device(rt.ctx, ptr, buf.ctypes.data, buf.nbytes))
+
+        def guard(fn):
+            def wrapped(*args):
+                try:
+                    fn(*args)
+                    return 0
+                except BaseException as exc:  # noqa: BLE001 -- reported through the C return code
+                    self.error = exc
+                    return 1
+            return wrapped
+
+        @guard
+        def all_gather(_user, d_send, d_recv, nbytes):
+            h2d(d_recv, self.all_gather_host(d2h(d_send, nbytes)).reshape(-1))
+
+        @guard
+        def all_reduce(_user, d_buf, count):
+            h2d(d_buf, self.all_reduce_sum_host(d2h(d_buf, count * 8).view(np.float64)))
+
+        @guard
+        def all_to_all(_user, d_send, soff, sbytes, d_recv, roff, rbytes):
+            send = [d2h(d_send + soff[p], sbytes[p]) for p in range(W)]
+            got = self.all_to_all_host(send, [rbytes[p] for p in range(W)])
+            for p in range(W):
+                if rbytes[p]:
+                    h2d(d_recv + roff[p], got[p])
+
+        cbs = (_lib.TRANSPORT_ALL_GATHER(all_gather), _lib.TRANSPORT_ALL_REDUCE(all_reduce),
+               _lib.TRANSPORT_ALL_TO_ALL(all_to_all))
+        struct = _lib.Transport(None, W, self.rank, *cbs)
+        self._keep = (cbs, struct)  # the callbacks must outlive the C calls
+        return struct
+
+
+def choose_exchange(n_features: int, n_factors: int, global_batch: int) -> str:
+    """"rows" when the touched rows of a global batch are estimated at under a quarter of the
+    dense gradient buffer (about two one-hot columns per row plus the side features are touched,
+    and the records travel twice -- to the owner and back); else "dense"."""
+    touched = min(n_features, 2 * global_batch + 256)
+    return "rows" if 4 * touched * (n_factors + 2) * 2 < n_features * (n_factors + 1) else "dense"
+
+
+class HipDpEngine:
+    """One rank's side of ``fit_data_parallel`` on the HIP kernels: the log replicated in HBM,
+    a training plan for this rank's shard size, and runs of iterations handed to
+    ``rfm_fm_fit_dp`` (gradients, exchange, update and both losses enqueued on the stream)."""
+
+    def __init__(self, model, train, val, world: int, rank: int, exchange: str, transport):
+        import numpy as np
+
+        from . import _lib
+        from .fm import FmPlan
+        from .runtime import BatchIdStream, DeviceCSR
+
+        rt = model._rt
+        self.rt, self.model, self.world, self.rank = rt, model, world, rank
+        X = train["features"]
+        if X.shape[1] != model.n_features:
+            raise ValueError(f"train features have {X.shape[1]} columns, model has {model.n_features}")
+        self.global_batch = model.batch_size
+        self.ids = BatchIdStream(rt, X.shape[0], self.global_batch, model.n_epochs, need_host=False)
+        try:
+            self.tr = X if isinstance(X, DeviceCSR) else DeviceCSR(rt, X)
+            self.y = rt.upload(np.asarray(train["labels"]), dtype=np.float64)
+            self.p = rt.upload(np.asarray(train["pscores"]), dtype=np.float64)
+            vX = val["features"]
+            self.va = vX if isinstance(vX, DeviceCSR) else DeviceCSR(rt, vX)
+            self.vy = rt.upload(np.asarray(val["labels"]), dtype=np.float64)
+            self.vp = rt.upload(np.asarray(val["pscores"]), dtype=np.float64)
+            lo, hi = shard_bounds(self.global_batch, world, 0)  # rank 0 holds a largest shard
+            hot = -2 if model.deterministic else model.hot_min_count
+            self.plan = FmPlan(rt, self.tr, self.y, self.p, model.n_factors, max(hi - lo, 1), hot)
+        except BaseException:
+            self.ids.close()
+            raise
+        self.exchange = {"dense": 0, "rows": 1}[exchange]
+        self.transport = transport
+        self._c_transport = transport.c_struct() if transport is not None else None
+        self.tl = rt.empty((model.n_epochs,), self.y.dtype)
+        self.vl = rt.empty((model.n_epochs,), self.y.dtype)
+        self.has_val = self.va.shape[0] > 0
+        if not self.has_val:
+            self.vl.fill_(float("nan"))
+        self._lib = _lib
+
+    def chunks(self):
+        for first, _host, dev_ids in self.ids.chunks():
+            yield first, dev_ids.shape[0], dev_ids
+
+    def run(self, first: int, count: int, chunk_first: int, dev_ids) -> None:
+        import ctypes as C
+
+        from .base import LOSS_EPS
+
+        m, rt, B = self.model, self.rt, self.global_batch
+        ids_ptr = dev_ids.data_ptr() + (first - chunk_first) * B * 4
+        tp = C.byref(self._c_transport) if self._c_transport is not None else None
+        rc = rt.lib.rfm_fm_fit_dp(
+            rt.ctx, self.plan.handle, tp, self.exchange, ids_ptr, B, count,
+            m.w0.dev.data_ptr(), m.w.dev.data_ptr(), m.V.dev.data_ptr(), float(m.lr),
+            self.va.indptr.data_ptr(), self.va.indices.data_ptr(), self.va.values.data_ptr(),
+            self.vy.data_ptr(), self.vp.data_ptr(), self.va.shape[0], LOSS_EPS,
+            self.tl.data_ptr() + first * 8, self.vl.data_ptr() + first * 8 if self.has_val else None)
+        if rc != 0 and self.transport is not None and self.transport.error is not None:
+            raise self.transport.error
+        self._lib.check(rc)
+
+    def predict(self, X):
+        return self.model.predict(X=X)
+
+    def losses(self):
+        self.rt.sync()
+        return self.tl.cpu().numpy().tolist(), self.vl.cpu().numpy().tolist()
+
+    def close(self) -> None:
+        self.ids.close()
+        self.rt.sync()
+        self.plan.close()
+
+
+def fit_data_parallel(model, train: dict, val: dict, exchange: str = "auto", transport=None,
+                      engine_factory=None) -> tuple:
+    """``model.fit(train, val)`` over the ranks of the initialised ``torch.distributed`` group:
+    every rank calls this with the same model (same seed, hence the same initial parameters),
+    the same split and the GLOBAL ``batch_size``; returns the same two loss lists on every rank
+    (``src/fm.py:112``) and leaves every replica with the same parameters.
+
+    Per iteration (``src/fm.py:71-102``) the global batch -- ``resample(..., random_state=epoch)``
+    as ever -- is cut into contiguous shards (``shard_bounds``); each rank computes the batch-SUM
+    gradient of its shard, the shards are combined (``exchange``: "dense" all-reduce of
+    ``[G_V | g_w | g_w0]``, "rows" = touched rows through their owner, "auto" =
+    ``choose_exchange``), every replica applies the same update; the train loss of the batch
+    with the new parameters and the validation loss are computed as per-rank sums over row
+    shards and combined with ONE all-reduce per run of iterations.  The sums
+    differ from the single-GPU fit in summation order only.
+
+    ``transport``: None = RCCL inside the library (backend nccl: one process per GPU);
+    ``HostStagedTransport`` otherwise.  ``model.evaluator`` is called after every iteration on
+    every rank (the replicas are identical, so are the metrics), as ``src/fm.py:104-110``.
+    ``engine_factory`` replaces the arithmetic (tests)."""
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if model.n_epochs <= 0:
+        return [], []
+    if exchange == "auto":
+        exchange = choose_exchange(model.n_features, model.n_factors, model.batch_size)
+    if exchange not in ("dense", "rows"):
+        raise ValueError(f"exchange must be auto, dense or rows, got {exchange!r}")
+    if engine_factory is None:
+        if transport is None and world > 1:
+            rt = model._rt
+            if not getattr(rt, "_direct_rccl", False):
+                if dist.get_backend() != "nccl" or not init_direct_rccl(rt, world, rank):
+                    raise RuntimeError("no transport: backend nccl binds RCCL inside the library; other "
+                                       "backends need HostStagedTransport(world, rank, rt)")
+                rt._direct_rccl = True
+        engine_factory = HipDpEngine
+    engine = engine_factory(model, train, val, world, rank, exchange, transport)
+    try:
+        evaluator = getattr(model, "evaluator", None)
+        for chunk_first, count, ids in engine.chunks():
+            if evaluator is None:
+                engine.run(chunk_first, count, chunk_first, ids)
+                continue
+            for epoch in range(chunk_first, chunk_first + count):
+                engine.run(epoch, 1, chunk_first, ids)
+                scores = engine.predict(evaluator.features[model.model_name])
+                model.val_metrics.append(evaluator.evaluate(y_scores=scores, estimator=model.estimator))
+        return engine.losses()
+    finally:
+        engine.close()

@@ -337,3 +337,89 @@ def test_mf_user_partition_step(tmp_path, world):
         # (measured: 2 ranks 3 %, 3 ranks 8 % after five 500-row batches with Zipf items --
         # examples of different ranks that share an item do not see each other inside a batch)
         assert abs(got - exact["val_loss"][-1]) < 0.15 * abs(exact["val_loss"][-1])
+
+
+# ---------------------------------------------------------------------------
+# dist.fit_data_parallel (the multi-GPU fit()) and HostStagedTransport: product code; the
+# arithmetic plugged in is the NumPy engine of tests/np_dp_engine.py
+# ---------------------------------------------------------------------------
+DP_KW = dict(estimator="IPS", n_epochs=5, n_factors=6, lr=1e-3, batch_size=501, seed=12345)
+
+
+class _CountingEvaluator:
+    """An evaluator of the host-callback kind (src/fm.py:104-110)."""
+
+    def __init__(self, features):
+        self.features = {"FM": features}
+
+    def evaluate(self, y_scores, estimator):
+        return float(np.mean(y_scores)) + (0.0 if estimator == "IPS" else 1.0)
+
+
+def _dp_worker(rank, world, port, out_dir, exchange, with_evaluator):
+    from types import SimpleNamespace
+
+    import torch.distributed as dist
+
+    from np_dp_engine import NumpyDpEngine
+    from relevance_factorizationmachine_amd.dist import HostStagedTransport, fit_data_parallel
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        train, val = synth.make_log("coat", "FM", "IPS", seed=0)
+        model = SimpleNamespace(n_features=train["features"].shape[1], evaluator=None, **DP_KW)
+        if with_evaluator:
+            model.evaluator = _CountingEvaluator(val["features"])
+            model.val_metrics, model.model_name = [], "FM"
+        t = HostStagedTransport(world, rank)
+        if rank == 0:  # the transport's host API on ragged payloads
+            pass
+        ragged = [np.arange(3 * (rank + 1) + p, dtype=np.float64).view(np.uint8) for p in range(world)]
+        got = t.all_to_all_host(ragged, [8 * (3 * (s + 1) + rank) for s in range(world)])
+        for s in range(world):
+            np.testing.assert_array_equal(got[s].view(np.float64), np.arange(3 * (s + 1) + rank, dtype=np.float64))
+        np.testing.assert_array_equal(t.all_gather_host(np.array([rank, 7], dtype=np.int32)),
+                                      np.array([[r, 7] for r in range(world)], dtype=np.int32))
+        np.testing.assert_array_equal(t.all_reduce_sum_host(np.array([1.0, rank])),
+                                      np.array([world, world * (world - 1) / 2]))
+        engines = []
+
+        def factory(*a):
+            engines.append(NumpyDpEngine(*a))
+            return engines[-1]
+
+        tr, va = fit_data_parallel(model, train, val, exchange=exchange, transport=t, engine_factory=factory)
+        e = engines[0]
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), w0=e.w0, w=e.w, V=e.V, tr=np.array(tr), va=np.array(va),
+                 metrics=np.array(model.val_metrics if with_evaluator else []))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,exchange,with_evaluator", [(2, "dense", False), (2, "rows", True), (3, "rows", False),
+                                                          (3, "dense", True)])
+def test_fit_data_parallel_equals_single_process_fit(tmp_path, world, exchange, with_evaluator):
+    """Both loss curves, the parameters and the per-iteration evaluator values of the multi-rank
+    fit equal the single-process oracle fit; the replicas are bitwise identical."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_dp_worker, args=(world, _free_port(), str(tmp_path), exchange, with_evaluator), nprocs=world,
+             join=True)
+    train, val = synth.make_log("coat", "FM", "IPS", seed=0)
+    kw = {k: v for k, v in DP_KW.items() if k != "estimator"}
+    ev = _CountingEvaluator(val["features"])
+    ref = cpu_ref.fm_fit(train, val, **kw, score_hook=(lambda s: ev.evaluate(s, "IPS")) if with_evaluator else None,
+                         hook_features=val["features"] if with_evaluator else None)
+    outs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for o in outs:
+        for name in ("V", "w", "w0"):
+            assert np.max(np.abs(o[name] - ref[name])) < 1e-12, name
+        assert np.max(np.abs(o["tr"] - np.array(ref["train_loss"]))) < 1e-12
+        assert np.max(np.abs(o["va"] - np.array(ref["val_loss"]))) < 1e-12
+        if with_evaluator:
+            assert np.max(np.abs(o["metrics"] - np.array(ref["val_metrics"]))) < 1e-12
+    for o in outs[1:]:
+        for name in ("V", "w", "w0", "tr", "va"):
+            np.testing.assert_array_equal(outs[0][name], o[name])

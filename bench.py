@@ -329,6 +329,126 @@ def published_config(rt, only: str | None = None) -> dict:
     return out
 
 
+MF_CONFIGS = (
+    # name, synthetic shape, k, rows of the log, batch sizes
+    ("c2_kuairec_small_k16", "kuairec_small", 16, None, (2000,)),
+    ("c5_1m_x_100k_k128", "synthetic_1m", 128, 2_000_000, (2000, 65536)),
+)
+
+
+def mf_config(rt, only: str | None = None) -> dict:
+    """``extra.mf`` (BASELINE config 5; src/mf.py:97-108): the logistic-MF batch in its three
+    forms -- EXACT (the reference's strictly sequential per-example SGD through the level
+    schedule), HOGWILD (unordered, non-parity) and the user-range partition with one rank (the
+    exact batch through the multi-GPU code path) -- as step-only examples/s with the schedules
+    precomputed (as the FM headline has its row ids precomputed), the fit() wall, levels per
+    batch, the algorithmic fraction of the HBM roofline (4*k*s + 6*s + 16 bytes per
+    example) and the validation-loss gap of the non-parity mode against the exact fit."""
+    import torch
+
+    from relevance_factorizationmachine_amd import _lib, synth
+    from relevance_factorizationmachine_amd.dist import hip_mf_partition_worker
+    from relevance_factorizationmachine_amd.mf import DevicePairs, LogisticMatrixFactorization
+    from relevance_factorizationmachine_amd.runtime import mf_schedule_ex, sample_batches
+
+    out = {}
+    for name, shape_name, k, n_train, batches in MF_CONFIGS:
+        if only and only != name:
+            continue
+        shape = synth.SHAPES[shape_name]
+        train, val = synth.make_log(shape, "MF", "IPS", seed=0, n_train=n_train, n_val=min(shape.n_val, 20000))
+        pairs = train["features"]
+        n_rows = pairs.shape[0]
+        bytes_per_example = 4 * k * 8 + 6 * 8 + 16
+        h_y = np.ascontiguousarray(train["labels"], dtype=np.float64)
+        h_p = np.ascontiguousarray(train["pscores"], dtype=np.float64)
+        cache_cap = int(min(1024, (32 << 10) // ((k + 2) * 8)))
+        res = {"workload": f"{shape_name}-shaped (user, item) pairs {shape.n_users}x{shape.n_items}, Zipf(1.3) items, "
+                           f"N_train={n_rows}, MF k={k}, IPS, lr=0.01, reg=0.5",
+               "algorithmic_bytes_per_example": bytes_per_example}
+        for B in batches:
+            E = 40 if B <= 4096 else 8
+            kw = dict(estimator="IPS", n_factors=k, lr=0.01, batch_size=B, seed=12345, n_users=shape.n_users,
+                      n_items=shape.n_items, reg=0.5)
+            model = LogisticMatrixFactorization(n_epochs=E, **kw)
+            model.b = float(np.mean(train["labels"]))
+            tr = DevicePairs(rt, pairs)
+            y, p = rt.upload(h_y), rt.upload(h_p)
+            ids = sample_batches(n_rows, B, 0, E)
+            d_ids = rt.upload(ids)
+            params = (model.P.dev.data_ptr(), model.Q.dev.data_ptr(), model.b_u.dev.data_ptr(),
+                      model.b_i.dev.data_ptr())
+            # ---- exact: schedules derived and uploaded beforehand -------------------------
+            t0 = time.perf_counter()
+            sched = [mf_schedule_ex(tr.h_users[r], tr.h_items[r], h_y[r], h_p[r], shape.n_users, shape.n_items,
+                                    cache_cap) for r in ids]
+            sched_s = (time.perf_counter() - t0) / E
+            dev = [(rt.upload(ex.view(np.uint8)), lp, rt.upload(lp),
+                    rt.upload(ci if ci.size else np.zeros(1, np.int32)), int(ci.size)) for ex, lp, ci in sched]
+
+            def run_exact():
+                for d_ex, lp, d_lp, d_ci, n_ci in dev:
+                    _lib.check(rt.lib.rfm_mf_sgd_levels_ex(rt.ctx, d_ex.data_ptr(), lp.ctypes.data, d_lp.data_ptr(),
+                                                           len(lp) - 1, d_ci.data_ptr(), n_ci, *params, model.b, k,
+                                                           0.01, 0.5))
+
+            def run_hogwild():
+                for e in range(E):
+                    _lib.check(rt.lib.rfm_mf_sgd_hogwild(rt.ctx, tr.users.data_ptr(), tr.items.data_ptr(),
+                                                         y.data_ptr(), p.data_ptr(), d_ids.data_ptr() + e * B * 4, B,
+                                                         *params, model.b, k, 0.01, 0.5))
+
+            def timed(fn):
+                fn()
+                reg = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    fn()
+                    torch.cuda.synchronize()
+                    reg.append((time.perf_counter() - t0) / E)
+                return float(np.median(reg))
+
+            levels = [len(lp) - 1 for _, lp, _ in sched]
+            entry = {"batches_timed": E, "levels_per_batch": float(np.mean(levels)),
+                     "host_schedule_ms_per_batch": 1e3 * sched_s}
+            for mode, fn in (("exact", run_exact), ("hogwild", run_hogwild)):
+                dt = timed(fn)
+                entry[mode] = {"ms_per_batch": 1e3 * dt, "value": B / dt, "unit": "examples/s",
+                               "algorithmic_frac_of_hbm_peak": bytes_per_example * B / dt / 1e9 / HBM_PEAK_GBS}
+            entry["exact"]["us_per_level"] = 1e3 * entry["exact"]["ms_per_batch"] / max(np.mean(levels), 1)
+            # ---- user-range partition with one rank: the exact batch through that code path
+            pm = LogisticMatrixFactorization(n_epochs=E, **kw)
+            step, finish = hip_mf_partition_worker(rt, pm, train, 1, 0)
+            for it in range(2):
+                step.step(it, step.users_of(it))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_part = min(E, 10)
+            for it in range(2, 2 + n_part):
+                step.step(it, step.users_of(it))
+            finish()
+            dt = (time.perf_counter() - t0) / n_part
+            entry["user_partition_world1"] = {
+                "ms_per_batch": 1e3 * dt, "value": B / dt, "unit": "examples/s",
+                "what": "sampler + host schedule + upload + kernels per batch, not pipelined (dist.MfUserPartitionStep)"}
+            # ---- fit() wall and the loss gap of the non-parity mode -------------------------
+            fits = {}
+            for mode in ("exact", "hogwild"):
+                m = LogisticMatrixFactorization(n_epochs=E, **kw)
+                m.hogwild = mode == "hogwild"
+                t0 = time.perf_counter()
+                trl, val_l = m.fit(train, val)
+                fits[mode] = (time.perf_counter() - t0, val_l[-1], trl[-1])
+            entry["fit_wall"] = {m_: {"ms_per_iteration": 1e3 * v[0] / E, "value": E * B / v[0], "unit": "examples/s",
+                                      "final_val_loss": v[1]} for m_, v in fits.items()}
+            entry["hogwild_val_loss_gap_vs_exact"] = abs(fits["hogwild"][1] - fits["exact"][1]) / abs(fits["exact"][1])
+            res[f"batch_{B}"] = entry
+            del dev, model, pm, tr
+        out[name] = res
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -356,6 +476,8 @@ def main() -> None:
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes")
     ap.add_argument("--pmc-timeout", type=int, default=240)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--mf-only", default=None, metavar="NAME|all",
+                    help="run only extra.mf (c2_kuairec_small_k16, c5_1m_x_100k_k128 or all) and print it")
     ap.add_argument("--published-only", default=None, metavar="NAME|all",
                     help="run only extra.published_config (kuairec_fm_ips, coat_fm_ips or all) and print it: "
                          "the command the rocprofv3 profiles of the published operating point are taken from")
@@ -363,6 +485,11 @@ def main() -> None:
     if args.pmc_child:
         args.no_cpu_baseline = args.no_extra = args.no_pmc = True
 
+    if args.mf_only:
+        from relevance_factorizationmachine_amd.runtime import Runtime
+        res = mf_config(Runtime.get(0), None if args.mf_only == "all" else args.mf_only)
+        print(json.dumps({"mf": res}))
+        return
     if args.published_only:
         from relevance_factorizationmachine_amd.runtime import Runtime
         res = published_config(Runtime.get(0), None if args.published_only == "all" else args.published_only)
@@ -385,7 +512,7 @@ def main() -> None:
     import torch.distributed as dist
 
     from relevance_factorizationmachine_amd import _lib, synth
-    from relevance_factorizationmachine_amd.dist import hip_fm_train_dp, hip_fm_worker, init_direct_rccl
+    from relevance_factorizationmachine_amd.dist import hip_fm_worker, init_direct_rccl
     from relevance_factorizationmachine_amd.fm import FactorizationMachines, FmPlan
     from relevance_factorizationmachine_amd.runtime import DeviceCSR, Runtime, sample_batches
 
@@ -439,36 +566,15 @@ def main() -> None:
             _lib.check(rt.lib.rfm_fm_train(
                 rt.ctx, plan.handle, *csr_ptrs, d_ids.data_ptr() + first * B * 4, B, count, *params,
                 lr, None, None, None, None, None, 0, 1e-8, None, None))
-    elif args.exchange == "rows" or (args.exchange == "auto" and
-                                     4 * min(n, 2 * gB + 256) * (k + 2) * 2 < n * (k + 1)):
-        # (estimate: about two one-hot columns per row plus the side features are touched, and
-        # the records travel twice -- to the owner and back)
-        # touched rows only: every rank's gradient rows go to the rank that owns the column
-        # (reduce-scatter by ownership), the owner sums them in rank order and applies, and
-        # the updated rows come back (all-gather) -- SURVEY.md 8e option 1
-        from relevance_factorizationmachine_amd.dist import RowExchange, hip_fm_rows_worker
-
-        ex = RowExchange.for_torch(dist, world, rank, n, k, backend=args.backend)
-        worker = hip_fm_rows_worker(rt, plan, d_ids, gB, model, world, rank, lr, ex)
-        transport = f"torch.distributed/{args.backend} all_to_all_single"
-        collective = ("touched rows: all-to-all of (column, gradient row) lists to the owning rank, "
-                      "owner-side ordered sum + update, all-to-all of the updated rows back")
-
-        def run(first: int, count: int) -> None:
-            for it in range(first, first + count):
-                worker.step(it, gB)
     else:
-        grad = rt.empty((n * (k + 1) + 1,), torch.float64)
-        all_reduce = None
-        if args.backend != "nccl":  # rehearsal transport: stage through the host
-            def all_reduce(g):
-                h = g.cpu()
-                dist.all_reduce(h, op=dist.ReduceOp.SUM)
-                g.copy_(h)
-        worker = hip_fm_worker(rt, plan, csr, y, p, d_ids, gB, model, grad, world, rank, lr, all_reduce)
-        # preferred: the whole loop in one C call with RCCL on the compute stream; if RCCL
-        # cannot be bound directly, the same steps go through torch.distributed
-        direct = False
+        from relevance_factorizationmachine_amd.dist import HostStagedTransport, choose_exchange
+
+        rows = args.exchange == "rows" or (args.exchange == "auto" and choose_exchange(n, k, gB) == "rows")
+        # the whole loop of a timed region is ONE C call (rfm_fm_fit_dp): gradients of the shard,
+        # exchange and update enqueued on the compute stream; RCCL is called by the library
+        # itself.  Backends other than nccl (rehearsals on a box with fewer GPUs than ranks)
+        # stage the same exchanges through the host.
+        direct, staged, c_transport = False, None, None
         if args.backend == "nccl" and not args.no_direct_rccl:
             try:
                 direct = init_direct_rccl(rt, world, rank)
@@ -477,14 +583,45 @@ def main() -> None:
             flag = torch.tensor([1 if direct else 0], device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks or none
             direct = bool(flag.item())
-        transport = "rccl-direct" if direct else f"torch.distributed/{args.backend}"
-        collective = (f"all-reduce(sum) of the dense [G_V|g_w|g_w0] buffer, "
-                      f"{8 * (n * (k + 1) + 1) / 1e6:.1f} MB")
+        elif args.backend != "nccl":
+            staged = HostStagedTransport(world, rank, rt=rt)
+            c_transport = staged.c_struct()
+        if rows:
+            collective = ("touched rows: gradient records to the rank that owns the column (all-to-all), "
+                          "owner-side rank-ordered sum + update, updated rows to every rank (all-to-all); "
+                          "transfer sizes derived from the row ids before the loop")
+        else:
+            collective = (f"all-reduce(sum) of the dense [G_V|g_w|g_w0] buffer, "
+                          f"{8 * (n * (k + 1) + 1) / 1e6:.1f} MB")
+        if direct or staged is not None:
+            transport = "rccl-direct (rfm_fm_fit_dp)" if direct else f"host-staged {args.backend} (rfm_fm_fit_dp)"
 
-        def run(first: int, count: int) -> None:
-            if direct:
-                hip_fm_train_dp(rt, plan, d_ids, gB, first, count, model, grad, world, rank, lr)
-            else:
+            def run(first: int, count: int) -> None:
+                rc = rt.lib.rfm_fm_fit_dp(
+                    rt.ctx, plan.handle, C.byref(c_transport) if c_transport is not None else None,
+                    1 if rows else 0, d_ids.data_ptr() + first * gB * 4, gB, count, *params, lr,
+                    None, None, None, None, None, 0, 1e-8, None, None)
+                if rc != 0 and staged is not None and staged.error is not None:
+                    raise staged.error
+                _lib.check(rc)
+        elif rows:
+            # fallback (RCCL could not be bound by the library): the exchange step by step through
+            # torch.distributed
+            from relevance_factorizationmachine_amd.dist import RowExchange, hip_fm_rows_worker
+
+            ex = RowExchange.for_torch(dist, world, rank, n, k, backend=args.backend)
+            worker = hip_fm_rows_worker(rt, plan, d_ids, gB, model, world, rank, lr, ex)
+            transport = f"torch.distributed/{args.backend} all_to_all_single (per-step host sync)"
+
+            def run(first: int, count: int) -> None:
+                for it in range(first, first + count):
+                    worker.step(it, gB)
+        else:
+            grad = rt.empty((n * (k + 1) + 1,), torch.float64)
+            worker = hip_fm_worker(rt, plan, csr, y, p, d_ids, gB, model, grad, world, rank, lr, None)
+            transport = f"torch.distributed/{args.backend}"
+
+            def run(first: int, count: int) -> None:
                 for it in range(first, first + count):
                     worker.step(it, gB)
 
@@ -695,6 +832,7 @@ def main() -> None:
                     "algorithmic_frac": (fwd_b + upd_b) * 2000 / dt / 1e9 / HBM_PEAK_GBS}
                 plan2.close()
             out["extra"]["published_config"] = published_config(rt)
+            out["extra"]["mf"] = mf_config(rt)
             # variant (A): fit() exactly as the reference runs it (src/fm.py:71-102)
             fit = {}
             kw = dict(estimator="IPS", n_factors=k, lr=lr, seed=seed, n_features=n)

@@ -774,6 +774,42 @@ def main() -> None:
         }
         out["sampler"] = {"host_exact_mt19937_s_per_batch": sampler_s / n_batches,
                           "threads": min(os.cpu_count() or 1, 32)}
+        # the level the line itself declares as binding: the larger of the forward's measured
+        # HBM traffic and its LDS atomic-add path, each against its own peak
+        r = out["roofline"]
+        levels = {"hbm (counters)": r["frac_traffic"], "lds (ds_add_f64 path)": r["lds"]["frac_of_forward_launch"]}
+        levels = {kk: v for kk, v in levels.items() if v is not None}
+        if levels:
+            r["binding_level"] = max(levels, key=levels.get)
+            r["frac_binding"] = levels[r["binding_level"]]
+            r["frac_binding_all"] = levels
+        if not args.no_extra:
+            # R5 inside the timed region: the same step consuming its row ids as the pipelined exact
+            # sampler produces them FROM COLD (nothing cached: every iteration's MT19937 shuffle of
+            # arange(N) runs on the host cores inside the interval, first chunk included)
+            from relevance_factorizationmachine_amd.runtime import ID_CACHE, BatchIdStream
+
+            n_ws = 200
+            ID_CACHE.clear()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            stream = BatchIdStream(rt, n_train, B, n_ws, need_host=False)
+            try:
+                for first, _host, dev_ids in stream.chunks():
+                    _lib.check(rt.lib.rfm_fm_train(
+                        rt.ctx, plan.handle, *csr_ptrs, dev_ids.data_ptr(), B, dev_ids.shape[0], *params,
+                        lr, None, None, None, None, None, 0, 1e-8, None, None))
+                torch.cuda.synchronize()
+            finally:
+                stream.close()
+            dt_ws = time.perf_counter() - t0
+            ID_CACHE.clear()
+            out["extra"]["with_sampler"] = {
+                "steps": n_ws, "ms_per_step": 1e3 * dt_ws / n_ws, "value": n_ws * B / dt_ws, "unit": "examples/s",
+                "host_threads": min(os.cpu_count() or 1, 32),
+                "what": "the headline step with batch selection (R5: resample(..., random_state=epoch), exact "
+                        "MT19937 shuffle per iteration) INSIDE the timed region, from cold: sampler thread -> pinned "
+                        "buffer -> copy stream -> step; `value` above has the ids precomputed"}
         if not args.no_extra:
             # the bitwise-reproducible mode (hot sums on chip in a fixed order: hot_min_count = -2)
             det = {}

@@ -30,6 +30,7 @@
 #include "rfm_common.h"
 #include "rfm_fm_kernels.hpp"
 #include "rfm_fm_plan.h"
+#include "rfm_fm_prep.hpp"
 #include "rfm_fm_rows.hpp"
 
 static_assert(RFM_MAX_FACTORS <= 1024, "fm_finalize_kernel's LDS totals hold 1024+2 values");
@@ -222,12 +223,21 @@ void validate_ids(rfm_ctx* ctx, rfm_fm_plan* plan, const int32_t* d_ids, int64_t
   RFM_REQUIRE(!flags[1], "a row id occurs twice in one batch: the ids of a step must be distinct");
 }
 
+// a prepared step's inputs (rfm_fm_prep.hpp): the batch's row blocks in batch order and the
+// tasks' records of this iteration
+struct PrepView {
+  const Entry* E;
+  const double2* YP;
+  const PrepRec* rec;
+  const int32_t* cnt;
+};
+
 // the three launches of one step; grad == nullptr -> update in place
 void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
                   const int32_t* d_indices, const double* d_values, const double* d_y,
                   const double* d_pscore, const int32_t* d_row_ids, int64_t batch, double* d_w0,
                   double* d_w, double* d_V, double lr, double* d_grad, int32_t* d_touch = nullptr,
-                  int32_t touch_id = 0) {
+                  int32_t touch_id = 0, const PrepView* prep = nullptr) {
   const int k = plan->k;
   const Shape s = shape_for(k);
   (void)d_indptr;
@@ -258,6 +268,15 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   unsigned long long* bits_other =
       plan->slot_bits.as<unsigned long long>() + (1 - parity) * plan->bits_words;
   f.slot_bits = bits;
+  if (prep) {  // rows at their batch position, nothing to mark
+    f.ent = nullptr;
+    f.rows = nullptr;
+    f.ell = reinterpret_cast<const char*>(prep->E);
+    f.ell_yp = prep->YP;
+    f.row_ids = nullptr;
+    f.slot_mark = nullptr;
+    f.slot_bits = nullptr;
+  }
   f.n_hot = plan->n_hot;
   f.hot_rounds = plan->hot_rounds;
   f.hot_fixed = plan->hot_fixed ? 1 : 0;
@@ -305,6 +324,11 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
     c.hot_slab = plan->hot_slab.as<double>();
     c.n_slabs = geom.grid;
     c.err_partial = plan->err_partial.as<double>();
+    if (prep) {
+      c.prep_rec = prep->rec;
+      c.prep_cnt = prep->cnt;
+      c.err = plan->err.as<double>();
+    }
     const int grid = c.nb_tasks + c.n_hot + 1;  // tasks, then the hot columns, then w0
     // LDS: the groups' lists + parked records + head rows, or the hot workgroups' scratch
     const int gpb = kBlock / s.lpr;
@@ -319,12 +343,21 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
       if (chunked) {
         // one workgroup per (four tasks, chunk of 64 lanes x vec factors)
         const int n_chunks = ((k + s.vec - 1) / s.vec + 63) / 64;
-        if (s.vec == 2)
-          hipLaunchKernelGGL((fm_consume_kernel<64, 2, 1, true>), dim3(grid, n_chunks), dim3(kBlock),
-                             lds, ctx->stream, c);
+        const dim3 g2(grid, n_chunks);
+        if (s.vec == 2 && prep)
+          hipLaunchKernelGGL((fm_consume_kernel<64, 2, 1, true, true>), g2, dim3(kBlock), lds, ctx->stream, c);
+        else if (s.vec == 2)
+          hipLaunchKernelGGL((fm_consume_kernel<64, 2, 1, true, false>), g2, dim3(kBlock), lds, ctx->stream, c);
+        else if (prep)
+          hipLaunchKernelGGL((fm_consume_kernel<64, 1, 1, true, true>), g2, dim3(kBlock), lds, ctx->stream, c);
         else
-          hipLaunchKernelGGL((fm_consume_kernel<64, 1, 1, true>), dim3(grid, n_chunks), dim3(kBlock),
-                             lds, ctx->stream, c);
+          hipLaunchKernelGGL((fm_consume_kernel<64, 1, 1, true, false>), g2, dim3(kBlock), lds, ctx->stream, c);
+      } else if (prep) {
+#define RFM_CALL_CONS(L, Vv, N)                                                                      \
+  hipLaunchKernelGGL((fm_consume_kernel<L, Vv, N, false, true>), dim3(grid), dim3(kBlock), lds, \
+                     ctx->stream, c)
+        RFM_FOR_SINGLE_CHUNK_SHAPE(s, RFM_CALL_CONS);
+#undef RFM_CALL_CONS
       } else {
 #define RFM_CALL_CONS(L, Vv, N) \
   hipLaunchKernelGGL((fm_consume_kernel<L, Vv, N>), dim3(grid), dim3(kBlock), lds, ctx->stream, c)
@@ -366,6 +399,87 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   }
   ctx->prof_mark();
 }
+
+// The prepared steps of one rfm_fm_train call: chunks of plan->prep_iters iterations, two
+// chunk buffers alive (the chunk being trained on, the next one already laid out).
+struct PrepRun {
+  rfm_ctx* ctx;
+  rfm_fm_plan* plan;
+  const int32_t* d_ids;
+  int64_t batch, n_iters;
+  int per_chunk = 0, n_chunks = 0;
+  bool on = false;
+
+  PrepRun(rfm_ctx* c, rfm_fm_plan* p, const int32_t* ids, int64_t b, int64_t n, bool allowed)
+      : ctx(c), plan(p), d_ids(ids), batch(b), n_iters(n) {
+    // (a short call -- an evaluator between iterations -- would pay the three launches of a
+    // chunk for a handful of steps)
+    on = allowed && plan->prep_ok && n_iters >= 8 && plan->ell.p;
+    if (!on) return;
+    per_chunk = plan->prep_iters;
+    n_chunks = int((n_iters + per_chunk - 1) / per_chunk);
+    enqueue(0);
+    if (n_chunks > 1) enqueue(1);
+  }
+
+  void enqueue(int c) {
+    auto& ch = plan->prep[c % 2];
+    const size_t cap_it = size_t(plan->prep_iters), nt = size_t(plan->n_tasks), mb = size_t(plan->max_batch);
+    if (!ch.E.p) {
+      ch.E.alloc(cap_it * mb * size_t(plan->ell_stride));
+      ch.YP.alloc(cap_it * mb * 16);
+      ch.tmp.alloc(cap_it * nt * kPrepCap * sizeof(PrepTmp));
+      ch.rec.alloc(cap_it * nt * kPrepCap * sizeof(PrepRec));
+      ch.cnt.alloc(cap_it * nt * 4);
+      ch.flags.alloc(cap_it * 4);
+      RFM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ch.h_flags), cap_it * 4, hipHostMallocDefault));
+      RFM_HIP_CHECK(hipEventCreateWithFlags(&ch.ready, hipEventDisableTiming));
+    }
+    const int64_t first = int64_t(c) * per_chunk;
+    const int n_it = int(std::min<int64_t>(per_chunk, n_iters - first));
+    hipStream_t st = ctx->stream;
+    RFM_HIP_CHECK(hipMemsetAsync(ch.cnt.p, 0, size_t(n_it) * nt * 4, st));
+    RFM_HIP_CHECK(hipMemsetAsync(ch.flags.p, 0, size_t(n_it) * 4, st));
+    const Shape s = shape_for(plan->k);
+    const int64_t items = int64_t(n_it) * batch * s.lpr;
+    const int grid_a = int(std::max<int64_t>(1, std::min<int64_t>((items + kBlock - 1) / kBlock, int64_t(ctx->n_cu) * 32)));
+    hipLaunchKernelGGL(fm_prep_gather_kernel, dim3(grid_a), dim3(kBlock), 0, st, plan->ell.as<char>(),
+                       plan->ell_stride, plan->ell_yp.as<double2>(), s.lpr, d_ids + first * batch, batch,
+                       batch, n_it, int32_t(plan->task_words * 64), plan->n_tasks, ch.E.as<Entry>(),
+                       ch.YP.as<double2>(), ch.tmp.as<PrepTmp>(), ch.cnt.as<int32_t>());
+    const int64_t buckets = int64_t(n_it) * plan->n_tasks;
+    const int grid_b = int(std::max<int64_t>(1, std::min<int64_t>((buckets + 15) / 16, int64_t(ctx->n_cu) * 32)));
+    hipLaunchKernelGGL(fm_prep_sort_kernel, dim3(grid_b), dim3(kBlock), 0, st, ch.tmp.as<PrepTmp>(),
+                       ch.cnt.as<int32_t>(), plan->slots.as<SlotRec>(), plan->n_tasks, n_it,
+                       ch.rec.as<PrepRec>(), ch.flags.as<int32_t>());
+    RFM_HIP_CHECK(hipGetLastError());
+    RFM_HIP_CHECK(hipMemcpyAsync(ch.h_flags, ch.flags.p, size_t(n_it) * 4, hipMemcpyDeviceToHost, st));
+    RFM_HIP_CHECK(hipEventRecord(ch.ready, st));
+  }
+
+  // the view of iteration `it`, or false when the iteration is not prepared (a task with more
+  // than kPrepCap marks: it takes the bitmap path)
+  bool view(int64_t it, PrepView& v) {
+    if (!on) return false;
+    const int c = int(it / per_chunk), j = int(it % per_chunk);
+    auto& ch = plan->prep[c % 2];
+    if (j == 0) RFM_HIP_CHECK(hipEventSynchronize(ch.ready));  // its flags are on the host
+    if (ch.h_flags[j]) return false;
+    const size_t nt = size_t(plan->n_tasks);
+    v.E = reinterpret_cast<const Entry*>(ch.E.as<char>() + size_t(j) * size_t(batch) * size_t(plan->ell_stride));
+    v.YP = ch.YP.as<double2>() + size_t(j) * size_t(batch);
+    v.rec = ch.rec.as<PrepRec>() + size_t(j) * nt * kPrepCap;
+    v.cnt = ch.cnt.as<int32_t>() + size_t(j) * nt;
+    return true;
+  }
+
+  // after the last step of chunk c has been enqueued: its buffer is free for chunk c + 2
+  void done(int64_t it) {
+    if (!on) return;
+    const int c = int(it / per_chunk);
+    if ((it + 1) % per_chunk == 0 && c + 2 < n_chunks) enqueue(c + 2);
+  }
+};
 
 // Timing experiment (RFM_TRAIN_GRAPH): everything enqueued on the context's stream while this
 // object lives is captured into one hipGraph on a stream of its own (the legacy default stream
@@ -699,22 +813,26 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
     // RFM_TRAIN_GRAPH=1 (timing experiment): the run's launches captured into one hipGraph
     // and replayed once (GraphCapture restores the context's stream on every way out)
     static const bool as_graph = env_int("RFM_TRAIN_GRAPH", 0) != 0;
+    // (prepared steps wait for an event on the host at every chunk: not inside a capture)
+    PrepRun prepared(ctx, plan, d_ids, batch, n_iters, !as_graph);
     GraphCapture capture(ctx, as_graph && !ctx->profiling);
     int64_t run_first = 0;
     for (int64_t it = 0; it < n_iters; ++it) {
       const int32_t* ids = d_ids + it * batch;
       const int64_t slot = it - run_first;
+      PrepView pv{};
+      const bool is_prepared = prepared.view(it, pv);
       enqueue_step(ctx, plan, d_indptr, d_indices, d_values, d_y, d_pscore, ids, batch, d_w0,
-                   d_w, d_V, lr, nullptr);
+                   d_w, d_V, lr, nullptr, nullptr, 0, is_prepared ? &pv : nullptr);
       if (d_out_train_loss) {
         // same batch, new parameters (src/fm.py:90-96), through the plan's records
         FwdArgs f{};
         f.ent = plan->ent.as<Entry>();
         f.rows = plan->rows.as<RowRec>();
-        f.ell = plan->ell.as<char>();
+        f.ell = is_prepared ? reinterpret_cast<const char*>(pv.E) : plan->ell.as<char>();
         f.ell_stride = plan->ell_stride;
-        f.ell_yp = plan->ell_yp.as<double2>();
-        f.row_ids = ids;
+        f.ell_yp = is_prepared ? pv.YP : plan->ell_yp.as<double2>();
+        f.row_ids = is_prepared ? nullptr : ids;
         f.n_rows = batch;
         f.w0 = d_w0;
         f.w = d_w;
@@ -735,6 +853,7 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
         finish(run_first, kRun);
         run_first = it + 1;
       }
+      prepared.done(it);
     }
     finish(run_first, n_iters - run_first);
     capture.replay(n_iters);

@@ -805,6 +805,10 @@ struct ConsArgs {
   const double* hot_slab;
   int32_t n_slabs;
   const double* err_partial;  // [n_slabs] per-workgroup sums of the residual
+  // PREP form: the task's records and their number, the rows' residuals by batch position
+  const PrepRec* prep_rec;    // [tasks][kPrepCap]
+  const int32_t* prep_cnt;    // [tasks]
+  const double* err;          // [batch]
 };
 
 template <int VEC, int NC>
@@ -928,7 +932,11 @@ __device__ inline int group_scan(int v, int l) {
 // chunk lists the task's marks itself (same bitmap words: they hit in L2), so the words cannot be
 // cleared while a sibling may still read them: the bitmap is double-buffered by step parity and
 // chunk 0 clears the task's words of the OTHER buffer (the step before, long consumed).
-template <int LPR, int VEC, int NC, bool CH = false>
+// PREP: the task's marked entries come as records in slot order at a fixed place (prepared
+// ahead of the loop from the row ids, see PrepRec) instead of being discovered from the bitmap:
+// first load = the records, second level = residuals + Q / V rows, third = the stores.  Sums
+// and their order are those of the bitmap form, bit for bit.
+template <int LPR, int VEC, int NC, bool CH = false, bool PREP = false>
 __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
   static_assert(!CH || NC == 1, "the chunked form holds one chunk per lane group");
   constexpr int GPB = kBlock / LPR;  // tasks of a workgroup
@@ -976,20 +984,33 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
   const int task = int(blockIdx.x) * GPB + gb;
   const int W = a.task_words;
   const int32_t slot0 = task * W * 64;  // first slot of the task
-  // first loads: the task's bitmap words (one per lane and trip) and its description
+  // first loads: the task's bitmap words (one per lane and trip) -- or, PREP, its records --
+  // and its description
   unsigned long long wd[TRIPS];
+  PrepRec pr[PLANES];
+  int prep_n = 0;
+  if constexpr (PREP) {
 #pragma unroll
-  for (int u = 0; u < TRIPS; ++u) {
-    const int idx = u * LPR + l;
-    wd[u] = idx < W ? a.slot_bits[int64_t(task) * W + idx] : 0ull;
+    for (int pl = 0; pl < PLANES; ++pl) pr[pl] = a.prep_rec[int64_t(task) * kPrepCap + pl * LPR + l];
+    prep_n = a.prep_cnt[task];
+#pragma unroll
+    for (int u = 0; u < TRIPS; ++u) wd[u] = 0ull;
+  } else {
+#pragma unroll
+    for (int u = 0; u < TRIPS; ++u) {
+      const int idx = u * LPR + l;
+      wd[u] = idx < W ? a.slot_bits[int64_t(task) * W + idx] : 0ull;
+    }
   }
   const TaskRec tk = a.tasks[task];
+  if constexpr (!PREP) {
 #pragma unroll
-  for (int u = 0; u < TRIPS; ++u) {
-    if (CH) {
-      if (fb == 0 && u * LPR + l < W) a.slot_bits_other[int64_t(task) * W + u * LPR + l] = 0ull;
-    } else if (wd[u]) {
-      a.slot_bits[int64_t(task) * W + u * LPR + l] = 0ull;  // consumed: cleared at once
+    for (int u = 0; u < TRIPS; ++u) {
+      if (CH) {
+        if (fb == 0 && u * LPR + l < W) a.slot_bits_other[int64_t(task) * W + u * LPR + l] = 0ull;
+      } else if (wd[u]) {
+        a.slot_bits[int64_t(task) * W + u * LPR + l] = 0ull;  // consumed: cleared at once
+      }
     }
   }
 
@@ -1034,7 +1055,7 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
   // the chain over the group's list of `fill` marked slots
   const auto run_list = [&]() {
     // records and marks of the listed slots, parked in LDS by list position
-    {
+    if constexpr (!PREP) {
       SlotRec sr[PLANES];
       SlotMark mk[PLANES];
 #pragma unroll
@@ -1059,6 +1080,7 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
       const int nb = max(min(BATCH, fill - at), 0);
       WinRec rec[BATCH];
       Pack<VEC> qq[BATCH][NC], vv[BATCH][NC];
+      double ee[BATCH];
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
         rec[u] = wrec[u < nb ? at + u : 0];
@@ -1066,6 +1088,7 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
           rec[u].t = 0;
           rec[u].col = 0;
         }
+        if constexpr (PREP) ee[u] = a.err[rec[u].t];  // the row's residual, with its Q row
         // the entry's Q row, and the V row of its column in case the entry starts a new
         // column: fetched together, so that a run of one-entry columns (one-hot users and
         // items in a small batch) costs one round trip, not one per column
@@ -1093,12 +1116,21 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
 #pragma unroll
             for (int ch = 0; ch < NC; ++ch) vold[ch] = vv[u][ch];
           }
+          // (PREP: the record holds x; coef = err * x and cx = coef * x as the bitmap form parks them)
+          // (the two products are rounded on their own -- no contraction into the sums below --
+          // so that both forms add the same numbers)
+          double coef = rec[u].coef, cx = rec[u].cx;
+          if constexpr (PREP) {
+#pragma clang fp contract(off)
+            coef = ee[u] * rec[u].coef;
+            cx = coef * rec[u].coef;
+          }
 #pragma unroll
           for (int ch = 0; ch < NC; ++ch)
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) acc.m[ch][v] += rec[u].coef * qq[u][ch].v[v];
-          acc.gw += rec[u].coef;
-          acc.d += rec[u].cx;
+            for (int v = 0; v < VEC; ++v) acc.m[ch][v] += coef * qq[u][ch].v[v];
+          acc.gw += coef;
+          acc.d += cx;
         }
       }
       at += nb;
@@ -1106,8 +1138,27 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
     fill = 0;
   };
 
+  if constexpr (PREP) {
+    // passes of WIN records (one, but for a task with unusually many marks): park, run the chain
+    for (int base = 0; __ballot(base < prep_n); base += WIN) {
+      if (base > 0) {
 #pragma unroll
-  for (int u = 0; u < TRIPS; ++u) {
+        for (int pl = 0; pl < PLANES; ++pl) {
+          const int e = base + pl * LPR + l;
+          pr[pl] = a.prep_rec[int64_t(task) * kPrepCap + (e < kPrepCap ? e : 0)];
+        }
+      }
+      fill = max(min(prep_n - base, WIN), 0);
+#pragma unroll
+      for (int pl = 0; pl < PLANES; ++pl) {
+        const int e = pl * LPR + l;
+        if (e < fill) wrec[e] = WinRec{pr[pl].t, pr[pl].col, pr[pl].x, 0.0};
+      }
+      if (__ballot(fill > 0)) run_list();
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < (PREP ? 0 : TRIPS); ++u) {
     unsigned long long word = wd[u];
     const int32_t s0 = slot0 + (u * LPR + l) * 64;  // first slot of this lane's word
     // move the trip's marked slots into the list in lane (= slot) order, as many as the list
@@ -1129,7 +1180,7 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
       if (__ballot(word != 0ull)) run_list();
     }
   }
-  if (__ballot(fill > 0)) run_list();
+  if (!PREP && __ballot(fill > 0)) run_list();
 
   // ---- columns that run over several tasks of this workgroup -----------------------------
   // the last column of a tail-open task is still in `acc` (if it got any entry here); a

@@ -35,6 +35,23 @@ struct rfm_fm_plan {
   // lists (mine / received / everybody's updated rows), transfer-plan arrays, small scratch
   rfm::DevBuf dp_grad, dp_sums, dp_rows, dp_recv, dp_all, dp_bounds, dp_all_bounds, dp_seg,
       dp_range_lo, dp_small;
+  // prepared steps of rfm_fm_train (rfm_fm_prep.hpp): two chunk buffers, each holding the
+  // batch-ordered row blocks E / YP and the tasks' records (tmp -> rec, cnt) of prep_iters
+  // iterations, and the overflow flags of a chunk (device + pinned host copy + its event)
+  bool prep_ok = false;       // the plan's layout allows prepared steps (padded row blocks, small batches)
+  int32_t prep_iters = 0;     // iterations per chunk
+  int32_t n_tasks = 0;        // tasks of the plan (n_task_blocks x lane groups per workgroup)
+  struct PrepChunk {
+    rfm::DevBuf E, YP, tmp, rec, cnt, flags;
+    int32_t* h_flags = nullptr;  // pinned
+    hipEvent_t ready = nullptr;
+  } prep[2];
+  ~rfm_fm_plan() {
+    for (auto& c : prep) {
+      if (c.h_flags) (void)hipHostFree(c.h_flags);
+      if (c.ready) (void)hipEventDestroy(c.ready);
+    }
+  }
   rfm::DevBuf ids_seen, ids_flags;  // RFM_CHECK_IDS=1: validation of the steps' row ids
   int32_t ids_stamp = 0;
   size_t device_bytes() const {

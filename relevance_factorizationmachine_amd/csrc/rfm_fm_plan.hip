@@ -354,8 +354,11 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
   const int64_t max_len = h_flags[3];
   plan->max_row_len = int32_t(max_len);
   plan->hot_rounds = int32_t(std::max<int64_t>(1, (max_len + shp.lpr - 1) / shp.lpr));
-  if (nnz > 0 && max_len <= shp.lpr && forward_many_rows(ctx, max_batch, n_factors) &&
-      env_int("RFM_NO_ELL", 0) == 0) {
+  // ... and plans for small batches keep the row blocks too, as the source of PREPARED steps
+  // (rfm_fm_prep.hpp: rfm_fm_train lays the batches of many iterations out ahead of the loop)
+  const bool many_rows = forward_many_rows(ctx, max_batch, n_factors);
+  const bool want_prep = !many_rows && env_int("RFM_NO_PREP", 0) == 0;
+  if (nnz > 0 && max_len <= shp.lpr && (many_rows || want_prep) && env_int("RFM_NO_ELL", 0) == 0) {
     plan->ell_stride = int64_t(shp.lpr) * int64_t(sizeof(Entry));
     plan->ell.alloc(nr * size_t(plan->ell_stride));
     plan->ell_yp.alloc(nr * 16);
@@ -366,6 +369,15 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
     RFM_HIP_CHECK(hipStreamSynchronize(st));
     plan->ent.release();
     plan->rows.release();
+    if (want_prep) {
+      // iterations per chunk: what 384 MiB hold twice (two chunks are alive at a time)
+      plan->n_tasks = int32_t(n_blocks * GPB);
+      const size_t per_iter = size_t(max_batch) * (size_t(plan->ell_stride) + 16) +
+                              size_t(plan->n_tasks) * (size_t(kPrepCap) * 32 + 4);
+      const size_t fit = (size_t(env_int("RFM_PREP_MB", 384)) << 20) / std::max<size_t>(per_iter, 1);
+      plan->prep_iters = int32_t(std::min<size_t>(fit, 64));
+      plan->prep_ok = plan->prep_iters >= 8;
+    }
   }
   upload(plan->tasks, tasks.data(), tasks.size() * sizeof(TaskRec), st);
   upload(plan->split, split.data(), split.size() * sizeof(SplitCol), st);

@@ -54,4 +54,21 @@ struct SplitCol {      // a sparse-class column longer than a whole workgroup's 
   int32_t pad;
 };
 
+// Prepared steps (rfm_fm_train): what a step needs that depends on the row ids alone is laid
+// out ahead of the loop, many iterations per launch -- the batch's row blocks in batch order
+// and, per task, the batch's entries of the task's slots in slot order (PrepRec), at a fixed
+// place: a task's records are then the gradient launch's FIRST load.
+constexpr int kPrepCap = 64;  // records of a task kept in place (more: the iteration is not prepared)
+struct PrepTmp {  // as gathered, unordered
+  int32_t slot;
+  int32_t t;
+  double x;
+};
+struct PrepRec {  // in slot order
+  int32_t t;      // batch position of the entry's row
+  int32_t col;    // feature column
+  double x;       // feature value
+};
+
+
 }  // namespace rfm

@@ -692,7 +692,9 @@ __global__ __launch_bounds__(kBlock) void logloss_kernel(const double* y, const 
 // then added in group order.
 __device__ inline void ordered_rows_sum(const double* base, int rows, int width,
                                         double* scratch /*[kBlock]*/, double* tot /*[width]*/) {
-  constexpr int U = 16;
+  // (loads in flight per thread: one round covers the slabs of a small batch's forward --
+  // 125 workgroups at B = 2 000 -- with seven row groups at k = 32)
+  constexpr int U = 32;
   const int fw = width < kBlock ? width : kBlock;  // factor lanes per row group
   const int nsg = kBlock / fw;
   const int sg = threadIdx.x / fw, fl = threadIdx.x % fw;
@@ -863,16 +865,22 @@ __device__ inline void apply_column(const ColAcc<VEC, NC>& acc, const Pack<VEC> 
 
 // The same from a whole workgroup, sums in LDS: tot[0..k) = M, tot[k] = sum coef,
 // tot[k+1] = sum coef*x.
+// (vpre: the row as the caller read it before the sums were formed -- threadIdx.x + j * kBlock
+// -- so that the load is in flight beside the sums' own loads; null: read here)
+constexpr int kRowPre = (RFM_MAX_FACTORS + kBlock - 1) / kBlock;
 __device__ inline void apply_column_block(const double* tot, int32_t col, double* V, double* w,
                                           double* grad, int64_t n, int k, double lr,
-                                          int32_t* touch, int32_t touch_id) {
+                                          int32_t* touch, int32_t touch_id,
+                                          const double* vpre = nullptr) {
   const double gw = tot[k], d = tot[k + 1];
-  for (int f = threadIdx.x; f < k; f += kBlock) {
+  int j = 0;
+  for (int f = threadIdx.x; f < k; f += kBlock, ++j) {
     const int64_t at = int64_t(col) * k + f;
+    const double vold = vpre ? vpre[j] : V[at];
     if (grad)
-      grad[at] = d * V[at] - tot[f];
+      grad[at] = d * vold - tot[f];
     else
-      V[at] += lr * (tot[f] - d * V[at]);
+      V[at] = vold + lr * (tot[f] - d * vold);
   }
   if (threadIdx.x == 0) {
     if (grad) {
@@ -958,11 +966,18 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
     const int hb = int(blockIdx.x) - a.nb_tasks;
     double* tot = lds_raw + kBlock;
     if (hb < a.n_hot) {
-      // a hot column: the forward workgroups' slabs, in block order
+      // a hot column: the forward workgroups' slabs, in block order; the column's row of V is
+      // requested first, so that it arrives with the slabs and not after them
+      const int32_t col = a.hot_cols[hb];
+      double vpre[kRowPre];
+#pragma unroll
+      for (int j = 0; j < kRowPre; ++j) {
+        const int f = int(threadIdx.x) + j * kBlock;
+        vpre[j] = a.V[int64_t(col) * k + (f < k ? f : 0)];
+      }
       ordered_rows_sum(a.hot_slab + int64_t(hb) * a.n_slabs * (k + 2), a.n_slabs, k + 2, lds_raw,
                        tot);
-      apply_column_block(tot, a.hot_cols[hb], a.V, a.w, a.grad, a.n, k, a.lr, a.touch,
-                         a.touch_id);
+      apply_column_block(tot, col, a.V, a.w, a.grad, a.n, k, a.lr, a.touch, a.touch_id, vpre);
     } else {
       // w0 from the forward workgroups' residual sums
       double acc = 0.0;

@@ -354,10 +354,12 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
   const int64_t max_len = h_flags[3];
   plan->max_row_len = int32_t(max_len);
   plan->hot_rounds = int32_t(std::max<int64_t>(1, (max_len + shp.lpr - 1) / shp.lpr));
-  // ... and plans for small batches keep the row blocks too, as the source of PREPARED steps
-  // (rfm_fm_prep.hpp: rfm_fm_train lays the batches of many iterations out ahead of the loop)
+  // ... and, with RFM_PREP=1 (an experiment that is measured and NOT the default: it removes a
+  // dependent level from each of the step's launches and changes nothing measurable --
+  // profiles/r3i), plans for small batches keep the row blocks as the source
+  // of PREPARED steps (rfm_fm_prep.hpp)
   const bool many_rows = forward_many_rows(ctx, max_batch, n_factors);
-  const bool want_prep = !many_rows && env_int("RFM_NO_PREP", 0) == 0;
+  const bool want_prep = !many_rows && env_int("RFM_PREP", 0) != 0;
   if (nnz > 0 && max_len <= shp.lpr && (many_rows || want_prep) && env_int("RFM_NO_ELL", 0) == 0) {
     plan->ell_stride = int64_t(shp.lpr) * int64_t(sizeof(Entry));
     plan->ell.alloc(nr * size_t(plan->ell_stride));

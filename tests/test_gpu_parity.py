@@ -967,3 +967,32 @@ def test_deterministic_switch_gives_bitwise_reproducible_fits(rfm, shape, k, bat
     ref = cpu_ref.fm_fit(train, val, n_epochs=3, n_factors=k, lr=9e-6, batch_size=batch, seed=12345)
     assert rel_err(fits[0][0], ref["V"]) < TIGHT and rel_err(fits[0][1], ref["w"]) < TIGHT
     assert rel_err(fits[0][2], ref["train_loss"]) < TIGHT and rel_err(fits[0][3], ref["val_loss"]) < TIGHT
+
+
+@pytest.mark.parametrize("shape,k,batch,its", [("kuairec_small", 16, 2000, 24), ("kuairec_small", 400, 2000, 12),
+                                              ("coat", 8, 500, 70)])
+def test_prepared_steps_experiment_gives_the_same_fit(rfm, monkeypatch, shape, k, batch, its):
+    """RFM_PREP=1 (an opt-in experiment, off by default: profiles/r3i): the batches' row blocks and
+    the tasks' records of a chunk of iterations are laid out ahead of the loop and the gradient
+    launch takes its PREP form.  The sums and their order are those of the default form: in the
+    bitwise-reproducible mode the two fits are equal bit for bit -- more than one chunk here."""
+    pkg, _lib, runtime, rt = rfm
+    sh = synth.SHAPES[shape]
+    train, val = synth.make_log(sh, "FM", "IPS", seed=0)
+
+    def fit():
+        rt.clear_caches()  # (a remembered plan would keep the form it was built with)
+        m = pkg.FactorizationMachines(estimator="IPS", n_epochs=its, n_factors=k, lr=9e-6, batch_size=batch,
+                                      seed=12345, n_features=train["features"].shape[1])
+        m.deterministic = True
+        return m, m.fit(train, val)
+
+    monkeypatch.setenv("RFM_PREP_MB", "8")  # small chunks: several of them, and the hand-over between them
+    base, (tr0, va0) = fit()
+    monkeypatch.setenv("RFM_PREP", "1")
+    prep, (tr1, va1) = fit()
+    monkeypatch.delenv("RFM_PREP")
+    rt.clear_caches()
+    np.testing.assert_array_equal(prep.V(), base.V())
+    np.testing.assert_array_equal(prep.w(), base.w())
+    assert prep.w0(0) == base.w0(0) and tr1 == tr0 and va1 == va0

@@ -54,6 +54,8 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+L2_GATHER_GBS = 17800.0  # same guide, 'Indexed rows: gather': rows shared by every workgroup, 16.8-18.8 TB/s
+MALL_GATHER_GBS = 8600.0  # ... 38 MB table, uniformly random rows (Infinity Cache)
 STEP_KERNELS = ["fm_forward_kernel", "fm_consume_kernel", "fm_finalize_kernel"]
 
 
@@ -296,6 +298,38 @@ def published_config(rt, only: str | None = None) -> dict:
         split = info["split_columns"] > 0
         fwd_b, upd_b = algorithmic_bytes(z, k)
         plan.close()
+        # the validation forward (the largest launch of an iteration of fit() at this width): a
+        # pure gather of V rows.  V (n*k*8 bytes) is beyond one XCD's 4 MiB L2 at k = 400, so it is
+        # priced against the guide's gathered-row rates: rows served from the XCDs' L2
+        # (16.8-18.8 TB/s chip-wide) and from the Infinity Cache (8.6 TB/s)
+        vX = val["features"]
+        vcsr = DeviceCSR(rt, vX)
+        scores = rt.empty((vX.shape[0],), torch.float64)
+
+        def val_forward():
+            _lib.check(rt.lib.rfm_fm_forward(rt.ctx, vcsr.indptr.data_ptr(), vcsr.indices.data_ptr(),
+                                             vcsr.values.data_ptr(), None, vX.shape[0], *params, n, k,
+                                             scores.data_ptr()))
+        for _ in range(5):
+            val_forward()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            val_forward()
+        torch.cuda.synchronize()
+        vf = (time.perf_counter() - t0) / 100
+        gather = int(vX.nnz) * (k + 1) * 8
+        val_roof = {"rows": int(vX.shape[0]), "ms_per_launch": 1e3 * vf, "gathered_bytes": gather,
+                    "achieved": gather / vf / 1e9, "unit": "GB/s", "bound": "l2-gather",
+                    "peak": L2_GATHER_GBS, "frac": gather / vf / 1e9 / L2_GATHER_GBS,
+                    "frac_of_infinity_cache_gather": gather / vf / 1e9 / MALL_GATHER_GBS,
+                    "what": "nnz x (k+1) x 8 bytes of V / w rows gathered per launch of rfm_fm_forward on the "
+                            "validation split, 100 back-to-back launches (wall / 100); peaks: MI355X guide, "
+                            "'Indexed rows: gather' table"}
+        # the step's own L2 traffic in the same model: forward gathers, then every marked entry
+        # re-reads its Q row and every distinct column's row of V is read and written once
+        distinct = int(np.unique(X[sample_batches(X.shape[0], B, warm, 1)[0]].indices).shape[0])
+        step_l2 = int(B * z * (k + 1) * 8 + B * k * 8 + B * z * k * 8 + 2 * distinct * (k + 1) * 8)
         # fit() exactly as the reference runs it (both loss forwards per iteration)
         walls = {}
         kw = dict(estimator="IPS", n_factors=k, lr=lr, seed=12345, n_features=n, batch_size=B)
@@ -316,7 +350,10 @@ def published_config(rt, only: str | None = None) -> dict:
                                                               for i in range(3)])),
                      "hot_columns": info["hot_columns"], "tasks": info["tasks"], "task_words": info["task_words"],
                      "algorithmic_bytes_per_step": (fwd_b + upd_b) * B,
-                     "algorithmic_frac_of_hbm_peak": (fwd_b + upd_b) * B / dt / 1e9 / HBM_PEAK_GBS},
+                     "algorithmic_frac_of_hbm_peak": (fwd_b + upd_b) * B / dt / 1e9 / HBM_PEAK_GBS,
+                     "l2_bytes_per_step": step_l2, "l2_achieved_GBs": step_l2 / dt / 1e9,
+                     "frac_of_l2_gather_peak": step_l2 / dt / 1e9 / L2_GATHER_GBS},
+            "validation_forward_roofline": val_roof,
             "fit_wall": {"iterations": its, "ms_per_iteration": 1e3 * walls["cold"] / its,
                          "value": its * B / walls["cold"], "unit": "examples/s",
                          "ms_per_iteration_second_fit_same_log": 1e3 * walls["again"] / its,

@@ -969,8 +969,8 @@ def test_deterministic_switch_gives_bitwise_reproducible_fits(rfm, shape, k, bat
     assert rel_err(fits[0][2], ref["train_loss"]) < TIGHT and rel_err(fits[0][3], ref["val_loss"]) < TIGHT
 
 
-@pytest.mark.parametrize("shape,k,batch,its", [("kuairec_small", 16, 2000, 24), ("kuairec_small", 400, 2000, 12),
-                                              ("coat", 8, 500, 70)])
+@pytest.mark.parametrize("shape,k,batch,its", [("kuairec_small", 16, 2000, 150), ("kuairec_small", 400, 2000, 24),
+                                              ("coat", 8, 500, 150)])
 def test_prepared_steps_experiment_gives_the_same_fit(rfm, monkeypatch, shape, k, batch, its):
     """RFM_PREP=1 (an opt-in experiment, off by default: profiles/r3i): the batches' row blocks and
     the tasks' records of a chunk of iterations are laid out ahead of the loop and the gradient
@@ -987,7 +987,9 @@ def test_prepared_steps_experiment_gives_the_same_fit(rfm, monkeypatch, shape, k
         m.deterministic = True
         return m, m.fit(train, val)
 
-    monkeypatch.setenv("RFM_PREP_MB", "8")  # small chunks: several of them, and the hand-over between them
+    # (48 MiB of chunk buffers: 10 iterations per chunk at k = 400, 64 at the small factor counts --
+    # several chunks in every case, and the hand-over between the two buffers)
+    monkeypatch.setenv("RFM_PREP_MB", "48")
     base, (tr0, va0) = fit()
     monkeypatch.setenv("RFM_PREP", "1")
     prep, (tr1, va1) = fit()

@@ -255,3 +255,36 @@ def test_host_tie_resolution_equals_reference_val_evaluator():
         got = frame.resolve(g["scores"], scratch)
         assert got == ev.evaluate(y_scores=g["scores"], estimator=est) == float(g[f"val_dcg_{est}"])
     pd.testing.assert_frame_equal(ev.interaction_df.drop(columns=["y_score"]), before)
+
+
+def test_content_hash_reads_every_byte_and_ignores_the_thread_count():
+    """rfm_hash_bytes (what the upload caches compare before they trust a device copy): any
+    single-byte change anywhere moves the hash, the thread count does not."""
+    import ctypes as C
+
+    lib = _lib.load()
+
+    def h(arr, threads):
+        out = C.c_uint64(0)
+        a = np.ascontiguousarray(arr)
+        _lib.check(lib.rfm_hash_bytes(a.ctypes.data, a.nbytes, threads, C.byref(out)))
+        return out.value
+
+    rng = np.random.default_rng(3)
+    for nbytes in (0, 1, 7, 8, 31, 32, 33, 1 << 20, (1 << 20) + 5, 5 * (1 << 20) + 123):
+        buf = rng.integers(0, 256, size=nbytes, dtype=np.uint8)
+        base = h(buf, 1)
+        assert all(h(buf, t) == base for t in (2, 3, 8, 64))
+        for pos in sorted({0, nbytes // 3, nbytes // 2, max(nbytes - 9, 0), nbytes - 1} & set(range(nbytes))):
+            edited = buf.copy()
+            edited[pos] ^= 1
+            assert h(edited, 4) != base, (nbytes, pos)
+        if nbytes:
+            assert h(buf[:-1], 4) != base  # the length counts
+    # a 1 M-row label vector with ONE flipped label (the case a sampled fingerprint missed)
+    labels = (rng.random(1_000_000) < 0.5).astype(np.int64)
+    before = h(labels, 8)
+    labels[123_457] = 1 - labels[123_457]
+    assert h(labels, 8) != before
+    from relevance_factorizationmachine_amd.runtime import content_hash
+    assert content_hash(labels) == h(labels, 8)

@@ -390,11 +390,19 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
 #ifdef RFM_ABLATE
     if (f.ablate & 256) return;
 #endif
+    if (chunked) {
+      const dim3 g2(grid, ((k + s.vec - 1) / s.vec + 63) / 64);
+      if (s.vec == 2)
+        hipLaunchKernelGGL(fm_finalize_chunk_kernel<2>, g2, dim3(kBlock), 0, ctx->stream, fa, nb_short);
+      else
+        hipLaunchKernelGGL(fm_finalize_chunk_kernel<1>, g2, dim3(kBlock), 0, ctx->stream, fa, nb_short);
+    } else {
 #define RFM_CALL_FIN(L, Vv, N)                                                                 \
   hipLaunchKernelGGL((fm_finalize_kernel<L, Vv, N>), dim3(grid), dim3(kBlock), 0, ctx->stream, \
                      fa, nb_short)
-    RFM_FOR_SHAPE(s, RFM_CALL_FIN);
+      RFM_FOR_SINGLE_CHUNK_SHAPE(s, RFM_CALL_FIN);
 #undef RFM_CALL_FIN
+    }
     RFM_HIP_CHECK(hipGetLastError());
   }
   ctx->prof_mark();

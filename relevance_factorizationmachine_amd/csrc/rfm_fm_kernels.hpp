@@ -1361,6 +1361,103 @@ __global__ __launch_bounds__(kBlock) void fm_finalize_kernel(FinArgs a, int nb_s
   apply_column_block(tot, cc.col, a.V, a.w, a.grad, a.n, k, a.lr, a.touch, a.touch_id);
 }
 
+// The same for factor counts of several chunks per lane, one chunk of 64 x VEC factors per
+// workgroup (blockIdx.y), as fm_consume_kernel's CH form: a short column's partial rows (at
+// most kShortSplit = 8) are ONE round of loads, a long column's are summed by one thread per
+// factor of the chunk with 32 rows in flight; stamps ride with the rows and the column's row of
+// V is requested before the sums, so a workgroup's chain is two dependent levels instead of
+// eight (k = 400, B = 2 000: 8.1 -> 6.8 us per launch, profiles/r3j vs r3q).
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void fm_finalize_chunk_kernel(FinArgs a, int nb_short) {
+  constexpr int LPR = kWave, CW = kWave * VEC;
+  __shared__ double tot[CW + 2];
+  const int k = a.k;
+  const int b = blockIdx.x;
+  const int fb = int(blockIdx.y) * CW;
+  if (b < nb_short) {
+    constexpr int GPB = kBlock / LPR;
+    constexpr int CB = 8;  // = kShortSplit: every partial row of a short column in one round
+    const int l = threadIdx.x % LPR;
+    const int ci = b * GPB + threadIdx.x / LPR;
+    if (ci >= a.n_split_short) return;
+    const SplitCol cc = a.split[ci];
+    const int f = fb + l * VEC;
+    const int fc = f < k ? f : 0;
+    ColAcc<VEC, 1> acc;
+    acc.clear();
+    Pack<VEC> vold[1];
+    vold[0].load(a.V + int64_t(cc.col) * k + fc);
+    bool any = false;
+    for (int i = 0; i < cc.part_count; i += CB) {
+      Pack<VEC> mm[CB];
+      double gg[CB], dd[CB], ss[CB];
+#pragma unroll
+      for (int u = 0; u < CB; ++u) {
+        const double* row = a.parts + int64_t(cc.part_begin + (i + u < cc.part_count ? i + u : i)) * (k + 3);
+        mm[u].load(row + fc);
+        gg[u] = row[k];
+        dd[u] = row[k + 1];
+        ss[u] = row[k + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < CB; ++u) {
+        const bool ok = i + u < cc.part_count && ss[u] == a.stamp;
+        any = any || ok;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc.m[0][v] += ok ? mm[u].v[v] : 0.0;
+        acc.gw += ok ? gg[u] : 0.0;
+        acc.d += ok ? dd[u] : 0.0;
+      }
+    }
+    if (any)
+      apply_column<LPR, VEC, 1>(acc, vold, cc.col, a.V, a.w, a.grad, a.n, k, a.lr, l, a.touch, a.touch_id, fb);
+    return;
+  }
+  const SplitCol cc = a.split[a.n_split_short + (b - nb_short)];
+  const int fcnt = k - fb < CW ? k - fb : CW;  // factors of this chunk
+  const int j = threadIdx.x;                   // < fcnt: factor fb + j; fcnt, fcnt + 1: sum coef, sum coef * x
+  const bool live = j < fcnt + 2;
+  const int cidx = j < fcnt ? fb + j : k + (j - fcnt);
+  const double vold = a.V[int64_t(cc.col) * k + (j < fcnt ? fb + j : 0)];
+  double acc = 0.0;
+  bool any = false;
+  constexpr int U = 32;
+  for (int r0 = 0; r0 < cc.part_count; r0 += U) {
+    double v[U], st[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double* row = a.parts + int64_t(cc.part_begin + (r0 + u < cc.part_count ? r0 + u : r0)) * (k + 3);
+      v[u] = row[live ? cidx : 0];
+      st[u] = row[k + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = r0 + u < cc.part_count && st[u] == a.stamp;
+      any = any || ok;  // (the stamps are the same for every thread: uniform)
+      acc += ok ? v[u] : 0.0;
+    }
+  }
+  if (!any) return;  // an untouched column is left alone
+  if (live) tot[j] = acc;
+  __syncthreads();
+  const double gw = tot[fcnt], d = tot[fcnt + 1];
+  if (j < fcnt) {
+    const int64_t at = int64_t(cc.col) * k + fb + j;
+    if (a.grad)
+      a.grad[at] = d * vold - acc;
+    else
+      a.V[at] = vold + a.lr * (acc - d * vold);
+  }
+  if (j == 0 && fb == 0) {
+    if (a.grad) {
+      a.grad[a.n * k + cc.col] = -gw;
+      if (a.touch) a.touch[cc.col] = a.touch_id;
+    } else {
+      a.w[cc.col] += a.lr * gw;
+    }
+  }
+}
+
 // RFM_CHECK_IDS=1: the row ids of one step must lie in the log and be distinct (a row's
 // batch position is recorded with a plain store, so a repeated id would lose one of its
 // contributions).  seen[r] holds the stamp of the last iteration that named row r.

@@ -998,3 +998,55 @@ def test_prepared_steps_experiment_gives_the_same_fit(rfm, monkeypatch, shape, k
     np.testing.assert_array_equal(prep.V(), base.V())
     np.testing.assert_array_equal(prep.w(), base.w())
     assert prep.w0(0) == base.w0(0) and tr1 == tr0 and va1 == va0
+
+
+@pytest.mark.parametrize("k", [129, 130, 191, 257, 258, 300, 383, 384, 385, 400, 511])
+def test_fm_fit_every_chunk_count(rfm, k):
+    """Factor counts of several chunks per lane (2, 3, 4, 8 chunks of 64 lanes; one and two
+    factors per lane; the last chunk full, nearly empty, or one lane wide): the forward's
+    in-register chunks and the gradient launch's and the finalize's chunk-per-workgroup forms
+    against the oracle -- a log with four columns in every row (longer than a workgroup's
+    tasks: pieces + finalize, short and long), ragged rows and untouched columns; the step, the
+    dense gradient and the touched-row records."""
+    pkg, _lib, runtime, rt = rfm
+    from relevance_factorizationmachine_amd.fm import FmPlan
+    rng = np.random.default_rng(k)
+    train = _random_log(rng, 9000, 120, 0.04, 4)
+    val = _random_log(rng, 300, 120, 0.04, 4)
+    lr, batch, its = 2e-6, 3000, 3
+    model = _fm(pkg, n_factors=k, n_features=120, lr=lr, batch_size=batch, n_epochs=its, seed=5)
+    tr, va = model.fit(train, val)
+    assert model.plan_info["hot_columns"] == 0 and model.plan_info["split_columns"] > 0
+    ref = cpu_ref.fm_fit(train, val, n_epochs=its, n_factors=k, lr=lr, batch_size=batch, seed=5)
+    assert rel_err(model.V(), ref["V"]) < TIGHT and rel_err(model.w(), ref["w"]) < TIGHT
+    assert rel_err(model.w0(), ref["w0"]) < TIGHT
+    assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT
+    # gradient forms on a fresh model: dense, and as touched-row records
+    dev = runtime.DeviceCSR(rt, train["features"])
+    y = rt.upload(train["labels"], dtype=np.float64)
+    p = rt.upload(train["pscores"], dtype=np.float64)
+    plan = FmPlan(rt, dev, y, p, k, batch)
+    ids_h = runtime.sample_batches(dev.shape[0], batch, 1, 1)[0]
+    ids = rt.upload(ids_h)
+    m = _fm(pkg, n_factors=k, n_features=120, lr=lr, batch_size=batch, seed=5)
+    params = (m.w0.dev.data_ptr(), m.w.dev.data_ptr(), m.V.dev.data_ptr())
+    csr = (dev.indptr.data_ptr(), dev.indices.data_ptr(), dev.values.data_ptr(), y.data_ptr(), p.data_ptr())
+    w0, w, V = cpu_ref.fm_init(5, 120, k)
+    Xb = train["features"][ids_h]
+    _, g_w0, g_w, G_V = cpu_ref.fm_gradients(Xb, train["labels"][ids_h], train["pscores"][ids_h], w0, w, V)
+    grad = rt.empty((120 * k + 120 + 1,), y.dtype)
+    for _ in range(2):  # twice: the slot bitmap alternates between two buffers by step parity
+        _lib.check(rt.lib.rfm_fm_grad(rt.ctx, plan.handle, *csr, ids.data_ptr(), batch, *params, grad.data_ptr()))
+        gh = grad.cpu().numpy()
+        assert rel_err(gh[: 120 * k].reshape(120, k), G_V) < TIGHT and rel_err(gh[120 * k: -1], g_w) < TIGHT
+        assert abs(gh[-1] - g_w0) <= TIGHT * max(1.0, abs(g_w0))
+    rows = rt.empty((120, k + 2), y.dtype)
+    n_rows = rt.empty((1,), ids.dtype)
+    gw0 = rt.empty((1,), y.dtype)
+    _lib.check(rt.lib.rfm_fm_grad_rows(rt.ctx, plan.handle, ids.data_ptr(), batch, *params, rows.data_ptr(), 120,
+                                       n_rows.data_ptr(), gw0.data_ptr(), None, 0, None))
+    rec = rows.cpu().numpy()[: int(n_rows.cpu().numpy()[0])]
+    cols = rec[:, 0].astype(np.int64)
+    np.testing.assert_array_equal(cols, np.unique(Xb.indices))
+    assert rel_err(rec[:, 1: k + 1], G_V[cols]) < TIGHT and rel_err(rec[:, k + 1], g_w[cols]) < TIGHT
+    plan.close()

@@ -369,6 +369,8 @@ def published_config(rt, only: str | None = None) -> dict:
 MF_CONFIGS = (
     # name, synthetic shape, k, rows of the log, batch sizes
     ("c2_kuairec_small_k16", "kuairec_small", 16, None, (2000,)),
+    # the reference's published MF runs: k = 400, B = 2 000 (conf/setting/kuairec.yaml:50-59)
+    ("published_kuairec_small_k400", "kuairec_small", 400, None, (2000,)),
     ("c5_1m_x_100k_k128", "synthetic_1m", 128, 2_000_000, (2000, 65536)),
 )
 
@@ -386,7 +388,7 @@ def mf_config(rt, only: str | None = None) -> dict:
     from relevance_factorizationmachine_amd import _lib, synth
     from relevance_factorizationmachine_amd.dist import hip_mf_partition_worker
     from relevance_factorizationmachine_amd.mf import DevicePairs, LogisticMatrixFactorization
-    from relevance_factorizationmachine_amd.runtime import mf_schedule_ex, sample_batches
+    from relevance_factorizationmachine_amd.runtime import mf_cache_capacity, mf_schedule_ex, sample_batches
 
     out = {}
     for name, shape_name, k, n_train, batches in MF_CONFIGS:
@@ -399,7 +401,7 @@ def mf_config(rt, only: str | None = None) -> dict:
         bytes_per_example = 4 * k * 8 + 6 * 8 + 16
         h_y = np.ascontiguousarray(train["labels"], dtype=np.float64)
         h_p = np.ascontiguousarray(train["pscores"], dtype=np.float64)
-        cache_cap = int(min(1024, (32 << 10) // ((k + 2) * 8)))
+        cache_cap = mf_cache_capacity(k)
         res = {"workload": f"{shape_name}-shaped (user, item) pairs {shape.n_users}x{shape.n_items}, Zipf(1.3) items, "
                            f"N_train={n_rows}, MF k={k}, IPS, lr=0.01, reg=0.5",
                "algorithmic_bytes_per_example": bytes_per_example}

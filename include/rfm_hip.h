@@ -364,8 +364,9 @@ int32_t rfm_mf_sgd_levels(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d
  * -1 = the item occurs once, -2 = repeated without a slot); gap = levels between the
  * example and the previous writer of its user row (RFM_MF_NO_WRITER if none), i.e.
  * how far ahead of its level the row is final and may be read.  The cached rows must
- * fit 32 KiB: cache_cap <= 32768 / (8 * (n_factors + 2)).  Capacities: h_ex batch records, h_level_ptr batch+1,
+ * fit the kernel's LDS: cache_cap <= rfm_mf_cache_capacity(n_factors) (32 KiB of rows, at most 1024).  Capacities: h_ex batch records, h_level_ptr batch+1,
  * h_cache_items cache_cap. */
+int32_t rfm_mf_cache_capacity(int32_t n_factors, int32_t* h_out);
 int32_t rfm_mf_schedule_ex(const int32_t* h_users, const int32_t* h_items, const double* h_y,
                            const double* h_pscore, int64_t batch, int32_t n_users,
                            int32_t n_items, int32_t cache_cap, void* h_ex,

@@ -143,6 +143,7 @@ SIGNATURES = {
     "rfm_comm_init": [_vp, _i32, _i32, _vp],
     "rfm_allreduce_sum": [_vp, _vp, _i64],
     "rfm_comm_destroy": [_vp],
+    "rfm_mf_cache_capacity": [_i32, C.POINTER(_i32)],
     "rfm_mf_schedule_ex": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, C.POINTER(_i32), _vp,
                            C.POINTER(_i32)],
     "rfm_mf_sgd_levels_ex": [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _f64, _i32, _f64,

@@ -12,6 +12,7 @@
 // ONE workgroup that walks the levels with a barrier in between, so a batch
 // whose popular item forms a long chain costs one launch, not one per level.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 
 #include "rfm_common.h"
@@ -326,7 +327,7 @@ constexpr int kMfAhead = RFM_MF_READ_AHEAD;
 static_assert(kMfAhead == 4, "the level loop below is unrolled for four slots");
 constexpr int kSeqMaxLevels = 1024;  // per launch: level pointers, 4 KiB of LDS
 constexpr int kSeqMaxRecs = 1024;    // per launch: example records, 24 KiB of LDS
-constexpr int kSeqMaxCacheBytes = 32 << 10;
+constexpr int kSeqMaxCacheBytes = 32 << 10;  // (96 KiB measured no faster at k = 16 ... 400: more rows to copy in and write back per launch)
 
 template <int VEC, int NC>
 struct MfSlot {
@@ -415,11 +416,17 @@ __device__ __forceinline__ void mf_slot_run(const MfExArgs& a, const MfSeqLds& m
 
 // levels [lo, hi) (at most kSeqMaxLevels, kSeqMaxRecs examples, each level of at most
 // kSeqBlock/LPR examples); a.rec_lo / a.rec_hi = level_ptr[lo] / level_ptr[hi]
+// (BLOCK: 1024 threads for one chunk of factors per lane; 512 for two to four chunks -- the
+// reference's published k = 300 / 400 -- whose ring of four slots needs 128 + VGPRs: eight lane
+// groups then, and more than four chunks run without the ring)
+constexpr int seq_block(int nc) { return nc > 1 ? 512 : kSeqBlock; }
+
 template <int LPR, int VEC, int NC>
-__global__ __launch_bounds__(kSeqBlock) void mf_sgd_seq_ex_kernel(MfExArgs a) {
+__global__ __launch_bounds__(seq_block(NC)) void mf_sgd_seq_ex_kernel(MfExArgs a) {
   extern __shared__ double seq_lds[];
-  // rows wider than one chunk per lane leave no registers for a ring of them
-  constexpr bool PF = NC <= 1;
+  constexpr int kSeqBlock = seq_block(NC);  // (shadows the one-chunk constant inside this kernel)
+  // rows wider than four chunks per lane leave no registers for a ring of them
+  constexpr bool PF = NC <= 4;
   const int l = threadIdx.x % LPR;
   const int g = threadIdx.x / LPR;
   const int k = a.k;
@@ -479,6 +486,21 @@ __global__ __launch_bounds__(kSeqBlock) void mf_sgd_seq_ex_kernel(MfExArgs a) {
     else if (f == k)
       a.bi[item] = qcache[i];
   }
+}
+
+// the sequential kernel with its dynamic-LDS limit raised where the item cache needs it
+// (remembered per device and instantiation)
+template <int L, int Vv, int N>
+static void launch_seq_ex(rfm_ctx* ctx, const MfExArgs& a, int threads, size_t lds) {
+  const auto kern = &mf_sgd_seq_ex_kernel<L, Vv, N>;
+  static std::atomic<bool> raised[64];
+  const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+  if (lds > (64u << 10) && !raised[dev].load(std::memory_order_relaxed)) {
+    RFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
+    raised[dev].store(true, std::memory_order_relaxed);
+  }
+  hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, ctx->stream, a);
 }
 
 static void mf_predict_launch(rfm_ctx* ctx, MfPredArgs a, double* d_out_loss) {
@@ -643,6 +665,13 @@ int32_t rfm_mf_sgd_levels(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d
   });
 }
 
+int32_t rfm_mf_cache_capacity(int32_t n_factors, int32_t* h_out) {
+  return guarded([&] {
+    RFM_REQUIRE(h_out && n_factors >= 1, "bad arguments");
+    *h_out = int32_t(std::min<int64_t>(1024, int64_t(kSeqMaxCacheBytes) / (int64_t(n_factors + 2) * 8)));
+  });
+}
+
 int32_t rfm_mf_sgd_levels_ex(rfm_ctx* ctx, const void* d_ex, const int32_t* h_level_ptr,
                              const int32_t* d_level_ptr, int32_t n_levels,
                              const int32_t* d_cache_items, int32_t n_cached, double* d_P,
@@ -671,7 +700,8 @@ int32_t rfm_mf_sgd_levels_ex(rfm_ctx* ctx, const void* d_ex, const int32_t* h_le
     a.lr = lr;
     a.reg = reg;
     // a level is "small" when the sequential workgroup covers it in one pass
-    const int seq_cap = kSeqBlock / s.lpr;
+    const int seq_threads = seq_block(s.nc);
+    const int seq_cap = seq_threads / s.lpr;
     int lev = 0;
     while (lev < n_levels) {
       const int cnt = h_level_ptr[lev + 1] - h_level_ptr[lev];
@@ -702,9 +732,7 @@ int32_t rfm_mf_sgd_levels_ex(rfm_ctx* ctx, const void* d_ex, const int32_t* h_le
         a.rec_hi = h_level_ptr[end];
         const size_t lds = size_t((end - lev + 2) / 2) * 8 + size_t(a.rec_hi - a.rec_lo) * sizeof(MfEx) +
                            cache_bytes;
-#define RFM_CALL_SEQ_EX(L, Vv, N)                                                              \
-  hipLaunchKernelGGL((mf_sgd_seq_ex_kernel<L, Vv, N>), dim3(1), dim3(kSeqBlock), lds, ctx->stream, \
-                     a)
+#define RFM_CALL_SEQ_EX(L, Vv, N) launch_seq_ex<L, Vv, N>(ctx, a, seq_threads, lds)
         RFM_FOR_SHAPE(s, RFM_CALL_SEQ_EX);
 #undef RFM_CALL_SEQ_EX
         lev = end;

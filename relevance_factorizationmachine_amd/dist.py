@@ -372,7 +372,7 @@ def hip_mf_partition_worker(rt, model, train: dict, world: int, rank: int, all_r
 
     from . import _lib
     from .mf import DevicePairs
-    from .runtime import mf_schedule_ex, sample_batches
+    from .runtime import mf_cache_capacity, mf_schedule_ex, sample_batches
 
     tr = DevicePairs(rt, train["features"])
     h_y = np.ascontiguousarray(train["labels"], dtype=np.float64)
@@ -381,7 +381,7 @@ def hip_mf_partition_worker(rt, model, train: dict, world: int, rank: int, all_r
     model.b = float(np.mean(train["labels"]))
     params = (model.P.dev.data_ptr(), model.Q.dev.data_ptr(), model.b_u.dev.data_ptr(),
               model.b_i.dev.data_ptr())
-    cache_cap = int(min(1024, (32 << 10) // ((k + 2) * 8)))
+    cache_cap = mf_cache_capacity(k)
     nq, ni = model.n_items * k, model.n_items
     sync = torch.cat([model.Q.dev.reshape(-1), model.b_i.dev.reshape(-1)]).clone()
     delta = torch.empty_like(sync)

@@ -18,7 +18,7 @@ from . import _lib
 from .base import LOSS_EPS, PointwiseBaseRecommender
 from .evaluate import EvalLoop, device_frame
 from .optimizer import DeviceSGD
-from .runtime import BatchIdStream, Runtime, mf_schedule_ex
+from .runtime import BatchIdStream, Runtime, mf_cache_capacity, mf_schedule_ex
 
 
 class _SchedulePipe:
@@ -203,8 +203,8 @@ class LogisticMatrixFactorization(PointwiseBaseRecommender):
         b = float(self.b)
         h_y = np.ascontiguousarray(train["labels"], dtype=np.float64)
         h_p = np.ascontiguousarray(train["pscores"], dtype=np.float64)
-        # item rows the sequential kernel may keep in LDS (32 KiB of rows + bias)
-        cache_cap = int(min(1024, (32 << 10) // ((self.n_factors + 2) * 8)))
+        # item rows the sequential kernel may keep in LDS (rows + bias, 32 KiB)
+        cache_cap = mf_cache_capacity(self.n_factors)
 
         ev_frame = ev_pairs = ev_loop = None
         if self.evaluator is not None:

@@ -469,6 +469,13 @@ MF_EX_DTYPE = np.dtype([("u", np.int32), ("i", np.int32), ("cslot", np.int32), (
                         ("ry", np.float64)])
 
 
+def mf_cache_capacity(n_factors: int) -> int:
+    """Item rows the sequential MF kernel may keep in LDS for a batch (``rfm_mf_cache_capacity``)."""
+    out = C.c_int32(0)
+    _lib.check(_lib.load().rfm_mf_cache_capacity(int(n_factors), C.byref(out)))
+    return int(out.value)
+
+
 def mf_schedule_ex(users: np.ndarray, items: np.ndarray, y: np.ndarray, pscore: np.ndarray,
                    n_users: int, n_items: int, cache_cap: int):
     """Level schedule of one batch as level-ordered records:

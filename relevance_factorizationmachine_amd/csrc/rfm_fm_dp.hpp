@@ -270,12 +270,16 @@ extern "C" int32_t rfm_fm_fit_dp(rfm_ctx* ctx, rfm_fm_plan* plan, const rfm_tran
     };
 
     TransferPlan tp;
-    const bool rows_mode = exchange == 1 && W > 1;
+    // (RFM_DP_FORCE_EXCHANGE=1: a single rank goes through the exchange too -- every collective
+    // with itself -- so that the whole multi-rank loop, RCCL calls included, can be run and
+    // checked on one GPU)
+    const bool exchange_on = W > 1 || env_int("RFM_DP_FORCE_EXCHANGE", 0) != 0;
+    const bool rows_mode = exchange == 1 && exchange_on;
     int32_t id0 = 0;
     if (rows_mode) {
       plan_transfers(ctx, plan, ex, d_ids, global_batch, lo, hi, n_iters, tp);
       id0 = next_touch_ids(ctx, plan, n_iters);
-    } else if (W > 1) {
+    } else if (exchange_on) {
       plan->dp_grad.ensure(size_t(count) * 8);
     }
     // small device scratch: [0] record count | [1..2] error flag | [8 .. 8+64) a step's real
@@ -293,7 +297,7 @@ extern "C" int32_t rfm_fm_fit_dp(rfm_ctx* ctx, rfm_fm_plan* plan, const rfm_tran
     int64_t run_first = 0;
     for (int64_t it = 0; it < n_iters; ++it) {
       const int32_t* ids = d_ids + it * global_batch + lo;
-      if (W == 1) {
+      if (!exchange_on) {
         enqueue_step(ctx, plan, nullptr, nullptr, nullptr, nullptr, nullptr, ids, batch, d_w0, d_w,
                      d_V, lr, nullptr);
       } else if (!rows_mode) {
@@ -387,7 +391,7 @@ extern "C" int32_t rfm_fm_fit_dp(rfm_ctx* ctx, rfm_fm_plan* plan, const rfm_tran
     }
     finish(run_first, n_iters - run_first);
     // the ranks' sums -> the losses, the same on every rank
-    if (W > 1 && (d_out_train_loss || want_val)) ex.all_reduce_sum(plan->dp_sums.as<double>(), 2 * n_iters);
+    if (exchange_on && (d_out_train_loss || want_val)) ex.all_reduce_sum(plan->dp_sums.as<double>(), 2 * n_iters);
     const int sgrid = int((n_iters + kBlock - 1) / kBlock);
     if (d_out_train_loss)
       hipLaunchKernelGGL(loss_scale_kernel, dim3(sgrid), dim3(kBlock), 0, st, sums_train, n_iters,

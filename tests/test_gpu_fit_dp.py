@@ -95,3 +95,39 @@ def test_fit_data_parallel_equals_single_gpu_fit(tmp_path, case, world, exchange
     for o in outs[1:]:  # every replica holds the same parameters and reports the same losses, bit for bit
         for name in ("V", "w", "w0", "tr", "va"):
             np.testing.assert_array_equal(outs[0][name], o[name])
+
+
+@pytest.mark.parametrize("exchange", ["rows", "dense"])
+def test_single_rank_through_the_rccl_exchange(exchange, monkeypatch):
+    """One rank, transport=None, RFM_DP_FORCE_EXCHANGE=1: the whole multi-rank loop of rfm_fm_fit_dp
+    with the library's OWN RCCL binding (communicator of one rank: ncclAllGather of the transfer
+    plan, ncclAllReduce of the gradient / the loss sums; the all-to-alls reduce to the rank's own
+    block) must give the plain fit.  This is as much of the RCCL path as one GPU can run."""
+    import ctypes as C
+
+    import relevance_factorizationmachine_amd as pkg
+    from relevance_factorizationmachine_amd import _lib
+    from relevance_factorizationmachine_amd.dist import HipDpEngine
+
+    monkeypatch.setenv("RFM_DP_FORCE_EXCHANGE", "1")
+    model, train, val = _make("small_k16", False)
+    rt = model._rt
+    uid = (C.c_uint8 * 128)()
+    _lib.check(rt.lib.rfm_comm_unique_id(uid))
+    _lib.check(rt.lib.rfm_comm_init(rt.ctx, 1, 0, uid))
+    try:
+        engine = HipDpEngine(model, train, val, 1, 0, exchange, None)
+        try:
+            for first, count, ids in engine.chunks():
+                engine.run(first, count, first, ids)
+            tr, va = engine.losses()
+        finally:
+            engine.close()
+    finally:
+        _lib.check(rt.lib.rfm_comm_destroy(rt.ctx))
+    monkeypatch.delenv("RFM_DP_FORCE_EXCHANGE")
+    ref, _, _ = _make("small_k16", False)
+    tr0, va0 = ref.fit(train, val)
+    assert rel_err(model.V(), ref.V()) < 1e-12 and rel_err(model.w(), ref.w()) < 1e-12
+    assert rel_err(model.w0(), ref.w0()) < 1e-12
+    assert rel_err(tr, tr0) < 1e-12 and rel_err(va, va0) < 1e-12

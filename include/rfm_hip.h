@@ -254,7 +254,10 @@ int32_t rfm_fm_set_rows(rfm_ctx* ctx, const double* d_rows, int64_t n_rows,
  * loss of the SAME batch with the new parameters, then the validation loss.
  * d_out_train_loss / d_out_val_loss receive one value per iteration (either
  * may be NULL to skip that forward).  Everything is enqueued on the ctx
- * stream; nothing synchronises. */
+ * stream; nothing synchronises.  (Environment, experiments only: RFM_PREP=1 at plan creation
+ * makes calls of 8 or more iterations lay their batches out ahead of the loop -- same results bit
+ * for bit, one wait on an event per chunk of iterations; RFM_TRAIN_GRAPH=1 replays the call's
+ * launches as one hipGraph.) */
 int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
                      const int32_t* d_indices, const double* d_values, const double* d_y,
                      const double* d_pscore, const int32_t* d_ids, int64_t batch,
@@ -366,6 +369,8 @@ int32_t rfm_mf_sgd_levels(rfm_ctx* ctx, const int32_t* d_users, const int32_t* d
  * how far ahead of its level the row is final and may be read.  The cached rows must
  * fit the kernel's LDS: cache_cap <= rfm_mf_cache_capacity(n_factors) (32 KiB of rows, at most 1024).  Capacities: h_ex batch records, h_level_ptr batch+1,
  * h_cache_items cache_cap. */
+/* Item rows (with their bias) the sequential kernel may keep in LDS for one batch: the largest
+ * cache_cap rfm_mf_schedule_ex / rfm_mf_sgd_levels_ex accept for this factor count. */
 int32_t rfm_mf_cache_capacity(int32_t n_factors, int32_t* h_out);
 int32_t rfm_mf_schedule_ex(const int32_t* h_users, const int32_t* h_items, const double* h_y,
                            const double* h_pscore, int64_t batch, int32_t n_users,

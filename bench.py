@@ -27,7 +27,22 @@ What the line carries besides the contract's fields:
  * ``extra.fit_wall``: variant (A), ``FactorizationMachines.fit`` exactly as the
    reference runs it (second batch forward + per-iteration validation forward,
    sampler, uploads and plan build included) at B = 2 000 and 65 536, and
-   ``cpu_baseline.fit_wall`` for the oracle's reference-structured fit.
+   ``cpu_baseline.fit_wall`` for the oracle's reference-structured fit;
+ * ``extra.with_sampler``: the headline step with batch selection (R5) INSIDE the
+   timed region, from cold -- next to ``value``, whose row ids are precomputed;
+ * ``extra.published_config``: the operating point of every published run of the
+   reference (k = 400 / B = 2 000, k = 300 / B = 500): step, per-kernel averages,
+   fit() wall, the validation forward priced against the L2 gather rate, and
+   ``vs_baseline`` against the examples/s derived from the reference's own run logs
+   (``--published-only NAME`` runs just that: the command the rocprofv3 profiles of
+   profiles/r3*/ are taken from);
+ * ``extra.mf``: BASELINE config 5 -- logistic MF exact / HOGWILD / user-partition
+   throughput, levels per batch, roofline fraction, loss gap (``--mf-only NAME``);
+ * ``roofline.binding_level`` / ``frac_binding``: the level the line declares as
+   binding (counter traffic vs the LDS atomic-add path), beside the algorithmic
+   ``frac`` kept for continuity.
+For N > 1 (``python -m torch.distributed.run ... bench.py --gpus N``) a timed region is
+ONE C call per rank (``rfm_fm_fit_dp``: gradients of the shard, RCCL exchange, update).
 """
 from __future__ import annotations
 

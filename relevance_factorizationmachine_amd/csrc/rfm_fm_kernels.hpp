@@ -130,7 +130,8 @@ struct FwdArgs {
 #else
 #define RFM_KEEP(a, bit) true
 #endif
-// bits: 1 slot marks, 2 Q store, 4 V gathers, 8 hot LDS adds, 16 slab store, 32 hot pass
+// bits: 1 slot marks, 2 Q store, 4 V gathers, 8 hot LDS adds, 16 slab store, 32 hot pass,
+// 512 no adds of the five most frequent columns after a workgroup's first trip
 
 // A row is handled by LPR consecutive lanes; lane l holds factors
 // (c*LPR + l)*VEC .. +VEC-1 for c < NC.  k=32 -> LPR=16, VEC=2: one 16-byte
@@ -603,6 +604,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
             const double coef = err[i] * eh[i].x;
             const double coef2 = pair01 ? err[R - 1] * eh[R - 1].x : 0.0;
             double* hrow = hot + (-1 - eh[i].slot) * hot_w;
+#ifdef RFM_ABLATE
+            // bit 512: what carrying the five most frequent columns (present in every row of the
+            // KuaiRec-shaped log) in registers across a workgroup's trips would save at best --
+            // their adds vanish on every trip after a workgroup's first
+            if ((a.ablate & 512) && -1 - eh[i].slot < 5 && base >= int64_t(gridDim.x) * (GPB * R)) continue;
+#endif
             if (RFM_KEEP(a, 8)) {
 #pragma unroll
               for (int c = 0; c < NC; ++c) {

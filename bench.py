@@ -485,7 +485,7 @@ def mf_config(rt, only: str | None = None) -> dict:
             dt = (time.perf_counter() - t0) / n_part
             entry["user_partition_world1"] = {
                 "ms_per_batch": 1e3 * dt, "value": B / dt, "unit": "examples/s",
-                "what": "sampler + host schedule + upload + kernels per batch, not pipelined (dist.MfUserPartitionStep)"}
+                "what": "dist.MfUserPartitionStep with one rank: sampler + host schedule of the next batch prepared by a worker thread, upload + kernels per batch"}
             # ---- fit() wall and the loss gap of the non-parity mode -------------------------
             fits = {}
             for mode in ("exact", "hogwild"):

@@ -386,23 +386,53 @@ def hip_mf_partition_worker(rt, model, train: dict, world: int, rank: int, all_r
     sync = torch.cat([model.Q.dev.reshape(-1), model.b_i.dev.reshape(-1)]).clone()
     delta = torch.empty_like(sync)
     keep = []
-    ids = {}
+    # The host side of a batch -- exact sampler, the rank's examples, their level schedule --
+    # depends on the iteration number alone: a worker thread prepares iteration it + 1 while the
+    # GPU runs iteration it (the calls release the GIL); a few iterations ahead, one thread each.
+    from concurrent.futures import ThreadPoolExecutor
+
+    import os
+
+    depth = max(1, min(8, (os.cpu_count() or 2) // 2))  # iterations prepared ahead, one thread each
+    pool = ThreadPoolExecutor(max_workers=depth, thread_name_prefix="rfm-mf-part")
+    ahead, cur = {}, {}
+    u_lo = user_ranges(model.n_users, world)
+
+    def prepare(it: int):
+        rows = sample_batches(tr.n, B, it, 1, n_threads=1)[0]
+        users = tr.h_users[rows]
+        pos = np.flatnonzero((users >= u_lo[rank]) & (users < u_lo[rank + 1]))
+        mine = rows[pos]
+        sched = (mf_schedule_ex(tr.h_users[mine], tr.h_items[mine], h_y[mine], h_p[mine], model.n_users,
+                                model.n_items, cache_cap) if pos.size else None)
+        return rows, pos, sched
+
+    def batch(it: int):
+        if cur.get("it") != it:
+            fut = ahead.pop(it, None)
+            cur.update(it=it, data=fut.result() if fut is not None else prepare(it))
+            for stale in [j for j in ahead if not it < j <= it + depth]:
+                ahead.pop(stale).cancel()
+            for nxt in range(it + 1, it + 1 + depth):
+                if nxt not in ahead:
+                    ahead[nxt] = pool.submit(prepare, nxt)
+        return cur["data"]
 
     def batch_rows(it: int) -> np.ndarray:
-        if it not in ids:
-            ids.clear()
-            ids[it] = sample_batches(tr.n, B, it, 1)[0]
-        return ids[it]
+        return batch(it)[0]
 
     def sgd_fn(it: int, positions: np.ndarray) -> None:
         if positions.size == 0:
             return
-        rows = batch_rows(it)[positions]
-        ex, level_ptr, cache_items = mf_schedule_ex(tr.h_users[rows], tr.h_items[rows], h_y[rows], h_p[rows],
-                                                    model.n_users, model.n_items, cache_cap)
+        rows_all, pos, sched = batch(it)
+        if sched is None or not np.array_equal(pos, positions):  # (positions other than the rank's own)
+            rows = rows_all[positions]
+            sched = mf_schedule_ex(tr.h_users[rows], tr.h_items[rows], h_y[rows], h_p[rows],
+                                   model.n_users, model.n_items, cache_cap)
+        ex, level_ptr, cache_items = sched
         d_ex, d_lptr = rt.upload(ex.view(np.uint8)), rt.upload(level_ptr)
         d_cache = rt.upload(cache_items if cache_items.size else np.zeros(1, np.int32))
-        keep.append((d_ex, d_lptr, d_cache))
+        keep.append((d_ex, d_lptr, d_cache, level_ptr))
         if len(keep) > 32:
             rt.sync()
             del keep[:-1]
@@ -435,6 +465,9 @@ def hip_mf_partition_worker(rt, model, train: dict, world: int, rank: int, all_r
 
     def finish() -> None:
         rt.sync()
+        for fut in ahead.values():
+            fut.cancel()
+        pool.shutdown(wait=True)
         if world == 1:
             return
         lo = step.lo

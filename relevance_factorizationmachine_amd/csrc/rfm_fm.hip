@@ -54,9 +54,10 @@ inline FwdGeom forward_geom(const rfm_ctx* ctx, int64_t n_rows, const Shape& s, 
   static const int per_cu = std::max(1, env_int("RFM_FWD_PER_CU", kBigBlock >= 1024 ? 1 : 2));
   static const int force = env_int("RFM_FWD_BLOCK", 0);
   FwdGeom g;
-  const int64_t rows_big = int64_t(kBigBlock / s.lpr) * rows_in_flight(s.nc);
+  // (the plain forward -- the caller's CSR arrays: predict, validation loss -- takes the same two
+  // shapes with its own number of rows per lane group)
+  const int64_t rows_big = int64_t(kBigBlock / s.lpr) * (records ? rows_in_flight(s.nc) : rows_in_flight_plain(s.nc));
   const int64_t blocks_big = (n_rows + rows_big - 1) / rows_big;
-  (void)records;  // the caller's CSR arrays (predict, validation loss) take the same shapes
   // (measured on config 3: the many-rows shape wins from about a third of a chip of such
   // workgroups: 16 384 rows 26 vs 30 us, 8 192 rows 21 vs 20 us)
   if (force != 256 && (force == 512 || blocks_big * 2 >= int64_t(ctx->n_cu) * per_cu)) {
@@ -103,7 +104,7 @@ void launch_forward_shape(rfm_ctx* ctx, const FwdArgs& a, const FwdGeom& geom, s
                           bool recs, bool fixed) {
   constexpr int R = rows_in_flight(N);
   if (geom.block == kBigBlock) {
-    if (!recs) return launch_forward_as<L, Vv, N, kBigBlock, R, false, false, false>(ctx, a, geom, lds);
+    if (!recs) return launch_forward_as<L, Vv, N, kBigBlock, rows_in_flight_plain(N), false, false, false>(ctx, a, geom, lds);
     if constexpr (hot_fixed_order(L, N, kBigBlock, R)) {
       if (fixed) {
         if (a.ell) return launch_forward_as<L, Vv, N, kBigBlock, R, true, true, true>(ctx, a, geom, lds);
@@ -144,7 +145,8 @@ void launch_forward(rfm_ctx* ctx, FwdArgs a, FwdGeom geom) {
   const bool fixed = recs && a.hot_fixed && a.n_hot > 0;
   const size_t lds =
       forward_lds_bytes(geom.block, s.lpr, s.vec, s.nc,
-                        geom.block == kBigBlock ? rows_in_flight(s.nc) : 1, a.n_hot, a.k, fixed);
+                        geom.block == kBigBlock ? (recs ? rows_in_flight(s.nc) : rows_in_flight_plain(s.nc)) : 1,
+                        a.n_hot, a.k, fixed);
   RFM_REQUIRE(lds <= (160u << 10), "forward kernel: %zu bytes of LDS", lds);
   RFM_REQUIRE(!fixed || a.hot_rounds >= 1, "hot_rounds unset");
 #define RFM_CALL_FWD(L, Vv, N) launch_forward_shape<L, Vv, N>(ctx, a, geom, lds, recs, fixed)

@@ -60,6 +60,15 @@ constexpr int kBigBlock = RFM_FWD_BIG_BLOCK;  // threads of the forward's many-r
 
 // rows a lane group works on concurrently (independent load chains in flight)
 constexpr int rows_in_flight(int nc) { return nc == 1 ? RFM_FWD_ROWS : 1; }
+// ... of the PLAIN forward (the caller's CSR arrays: predict, validation loss), which keeps no Q
+// row, leaves no marks and sums no hot class, so its registers hold more rows
+#ifndef RFM_FWD_ROWS_PLAIN
+#define RFM_FWD_ROWS_PLAIN RFM_FWD_ROWS
+#endif
+#ifndef RFM_FWD_PLAIN_UNROLL
+#define RFM_FWD_PLAIN_UNROLL RFM_FWD_BIG_UNROLL
+#endif
+constexpr int rows_in_flight_plain(int nc) { return nc == 1 ? RFM_FWD_ROWS_PLAIN : 1; }
 
 // Hot-class sums in a fixed order (training forward): the rows a workgroup holds in one trip
 // leave their Q rows and per-entry coefficients in LDS, every hot column gets the set of those
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
       const int cnt = (maxlen - pb) < LPR ? (maxlen - pb) : LPR;
       // entries whose gathers are in flight together: the many-rows shape is at its register
       // budget with two (x R rows); the one-row shape has registers to spare
-#pragma unroll(BLOCK == kBigBlock || NC > 1 ? (NC == 1 && !DET && (ELL || !REC) ? RFM_FWD_BIG_UNROLL : 2) : RFM_FWD_SMALL_UNROLL)
+#pragma unroll(BLOCK == kBigBlock || NC > 1 ? (NC == 1 && !DET && (ELL || !REC) ? (REC ? RFM_FWD_BIG_UNROLL : RFM_FWD_PLAIN_UNROLL) : 2) : RFM_FWD_SMALL_UNROLL)
       for (int j = 0; j < cnt; ++j) {
         Entry ej[R];
         Pack<VEC> pv[R][NC];

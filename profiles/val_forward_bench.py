@@ -25,9 +25,18 @@ for shape, k, n_val in (("kuairec_big", 32, 100_000), ("kuairec_big", 32, 20_000
         _lib.check(rt.lib.rfm_fm_forward(rt.ctx, d.indptr.data_ptr(), d.indices.data_ptr(), d.values.data_ptr(), None,
                                          X.shape[0], m.w0.dev.data_ptr(), m.w.dev.data_ptr(), m.V.dev.data_ptr(),
                                          X.shape[1], k, scores.data_ptr()))
-    for _ in range(10): fwd()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(200): fwd()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 200
-    out.append(f"{shape} k={k} rows={X.shape[0]}: {1e6*dt:.1f} us")
+    y = rt.upload(val["labels"], dtype=np.float64); p = rt.upload(val["pscores"], dtype=np.float64)
+    loss = rt.empty((1,), torch.float64)
+    def fwd_loss():
+        _lib.check(rt.lib.rfm_fm_forward_loss(rt.ctx, d.indptr.data_ptr(), d.indices.data_ptr(), d.values.data_ptr(),
+                                              y.data_ptr(), p.data_ptr(), None, X.shape[0], m.w0.dev.data_ptr(),
+                                              m.w.dev.data_ptr(), m.V.dev.data_ptr(), X.shape[1], k, 1e-8, None,
+                                              loss.data_ptr()))
+    res = []
+    for fn in (fwd, fwd_loss):
+        for _ in range(10): fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(200): fn()
+        torch.cuda.synchronize(); res.append((time.perf_counter() - t0) / 200)
+    out.append(f"{shape} k={k} rows={X.shape[0]}: {1e6*res[0]:.1f} us, with loss (+ finish launch) {1e6*res[1]:.1f} us")
 print(" | ".join(out))

@@ -87,6 +87,9 @@ inline size_t forward_lds_bytes(int block, int lpr, int vec, int nc, int rows, i
                                 bool fixed_order) {
   size_t bytes = size_t(block) * 8 + (size_t(block) * rows + size_t(block / lpr)) * sizeof(Entry) +
                  size_t(n_hot) * size_t(k + 2) * 8;
+  // (many-rows shape without a hot class -- the loss forwards: two stages of a trip's
+  // {score, label, propensity}, see the kernel)
+  if (block == kBigBlock && n_hot == 0) bytes += 2 * size_t(block / lpr) * rows * 24;
   if (fixed_order && n_hot > 0 && hot_fixed_order(lpr, nc, block, rows)) {
     const size_t rt = size_t(block / lpr) * rows;
     bytes += rt * size_t(lpr * vec) * 8;                                 // Q rows of the trip
@@ -191,6 +194,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
   const double w0 = a.w0[0];
   const int64_t last_row = a.n_rows - 1;
   double loss_acc = 0.0, err_acc = 0.0;
+  // many-rows shape, loss asked for, no hot class (whose sums would sit where the stages do)
+  const bool stage_loss = BLOCK == kBigBlock && a.loss_partial != nullptr && H == 0;
+  double* lstage = hot;  // [2][RT][3]
+  int trip = 0;
   // factor offsets of this lane; lanes past k read offset 0 and are masked
   int fo[NC];
   bool fok[NC];
@@ -413,11 +420,33 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
         if (l == 0) {
           if (a.out_pred) a.out_pred[t[i]] = pred;
           if (a.out_err) a.out_err[t[i]] = err[i];
-          if (a.loss_partial) loss_acc += logloss_term(yy[i], pp[i], pred, a.eps);
+          if (a.loss_partial) {
+            if (stage_loss) {  // the logarithms wait for the trip's barrier below
+              double* st = lstage + ((trip & 1) * RT + i * GPB + g) * 3;
+              st[0] = pred;
+              st[1] = yy[i];
+              st[2] = pp[i];
+            } else {
+              loss_acc += logloss_term(yy[i], pp[i], pred, a.eps);
+            }
+          }
           err_acc += err[i];
         }
+      } else if (stage_loss && l == 0) {
+        lstage[((trip & 1) * RT + i * GPB + g) * 3] = -1.0;  // no row here (a score is in [0, 1] or NaN)
       }
     }
+    if (stage_loss) {
+      // The two logarithms of a row's loss term are ~200 dependent f64 instructions; computed by
+      // lane 0 of every lane group they ran once per row and WAVE (validation forward, 100 k
+      // rows: 38 of 27 + us).  Staged, the trip's rows are spread over the workgroup's threads.
+      __syncthreads();
+      if (tid < RT) {
+        const double* st = lstage + ((trip & 1) * RT + tid) * 3;
+        if (!(st[0] < 0.0)) loss_acc += logloss_term(st[1], st[2], st[0], a.eps);
+      }
+    }
+    ++trip;
 
     int32_t touched[R];
     if (warm) {

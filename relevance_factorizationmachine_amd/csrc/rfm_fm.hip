@@ -82,9 +82,9 @@ bool forward_many_rows(const rfm_ctx* ctx, int64_t rows, int n_factors) {
 }
 
 // one instantiation: raises its dynamic-LDS limit when a launch needs more than the default
-template <int L, int Vv, int N, int BLOCK, int R, bool REC, bool ELL, bool DET>
+template <int L, int Vv, int N, int BLOCK, int R, bool REC, bool ELL, bool DET, bool SEG = false>
 void launch_forward_as(rfm_ctx* ctx, const FwdArgs& a, const FwdGeom& geom, size_t lds) {
-  const auto kern = &fm_forward_kernel<L, Vv, N, BLOCK, R, REC, ELL, DET>;
+  const auto kern = &fm_forward_kernel<L, Vv, N, BLOCK, R, REC, ELL, DET, SEG>;
   // (the attribute belongs to the function ON a device: kept per device; atomics because
   // contexts of different host threads share the instantiation)
   static std::atomic<size_t> lds_allowed[kMaxDevices];
@@ -170,6 +170,25 @@ void forward_loss(rfm_ctx* ctx, FwdArgs a, double* d_out_loss) {
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kBlock), 0, ctx->stream,
                      ctx->loss_partials.as<double>(), geom.grid, a.n_rows, d_out_loss);
   RFM_HIP_CHECK(hipGetLastError());
+}
+
+// The two loss forwards of a fit() iteration in ONE launch (fm_forward_kernel's SEG form): rows
+// a.row_ids[0 .. n_rows_a) of the training log (loss partials -> row_a) and every row of the
+// validation log (-> row_b).  Returns the number of partials per row, or -1 when the rows
+// together do not take the many-rows shape (the caller then launches the two separately).
+int forward_loss_pair_deferred(rfm_ctx* ctx, FwdArgs a, double* row_a, double* row_b) {
+  const Shape s = shape_for(a.k);
+  const FwdGeom geom = forward_geom(ctx, a.n_rows, s, false);
+  if (geom.block != kBigBlock || geom.grid > kMaxFwdGrid) return -1;
+  a.loss_partial = row_a;
+  a.loss_partial2 = row_b;
+  const size_t lds = forward_lds_bytes(geom.block, s.lpr, s.vec, s.nc, rows_in_flight_plain(s.nc), 0, a.k, false);
+#define RFM_CALL_SEG(L, Vv, N) \
+  launch_forward_as<L, Vv, N, kBigBlock, rows_in_flight_plain(N), false, false, false, true>(ctx, a, geom, lds)
+  RFM_FOR_SHAPE(s, RFM_CALL_SEG);
+#undef RFM_CALL_SEG
+  RFM_HIP_CHECK(hipGetLastError());
+  return geom.grid;
 }
 
 // forward with loss whose partials go to `partial_row` (kMaxFwdGrid doubles) and are
@@ -826,6 +845,15 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
     // (prepared steps wait for an event on the host at every chunk: not inside a capture)
     PrepRun prepared(ctx, plan, d_ids, batch, n_iters, !as_graph);
     GraphCapture capture(ctx, as_graph && !ctx->profiling);
+    // one decision for the whole call (the partials of a run are finished together).  Only for
+    // factor counts of several chunks per lane: there it saves a launch (k = 400, B = 2 000:
+    // 0.098 -> 0.090 ms per iteration of fit()); at one chunk per lane the batch's rows are
+    // faster through the plan's padded row blocks than through the CSR arrays (config 3:
+    // 104.7 vs 111.6 us per iteration at B = 65 536).  RFM_MERGE_LOSS=0 / 2: never / always.
+    const int merge_mode = env_int("RFM_MERGE_LOSS", 1);
+    const bool merge_call = merge_mode != 0 && (merge_mode == 2 || shape_for(plan->k).nc > 1) &&
+                            d_out_train_loss && d_out_val_loss && !prepared.on &&
+                            forward_geom(ctx, batch + n_val, shape_for(plan->k), false).block == kBigBlock;
     int64_t run_first = 0;
     for (int64_t it = 0; it < n_iters; ++it) {
       const int32_t* ids = d_ids + it * batch;
@@ -834,7 +862,27 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
       const bool is_prepared = prepared.view(it, pv);
       enqueue_step(ctx, plan, d_indptr, d_indices, d_values, d_y, d_pscore, ids, batch, d_w0,
                    d_w, d_V, lr, nullptr, nullptr, 0, is_prepared ? &pv : nullptr);
-      if (d_out_train_loss) {
+      // both losses asked for: ONE launch over the batch's rows of the training log and the
+      // validation log (RFM_MERGE_LOSS=0: two launches)
+      bool merged = false;
+      if (merge_call) {
+        FwdArgs f = forward_args(d_indptr, d_indices, d_values, ids, batch + n_val, d_w0, d_w, d_V, plan->k);
+        f.n_rows_a = batch;
+        f.y = d_y;
+        f.pscore = d_pscore;
+        f.indptr2 = d_val_indptr;
+        f.indices2 = d_val_indices;
+        f.values2 = d_val_values;
+        f.y2 = d_val_y;
+        f.pscore2 = d_val_pscore;
+        f.eps = eps;
+        const int parts = forward_loss_pair_deferred(ctx, f, train_rows + slot * kMaxFwdGrid,
+                                                     val_rows + slot * kMaxFwdGrid);
+        RFM_REQUIRE(parts > 0, "merged loss forward: unexpected geometry");
+        train_parts = val_parts = parts;
+        merged = true;
+      }
+      if (d_out_train_loss && !merged) {
         // same batch, new parameters (src/fm.py:90-96), through the plan's records
         FwdArgs f{};
         f.ent = plan->ent.as<Entry>();
@@ -851,7 +899,7 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
         f.eps = eps;
         train_parts = forward_loss_deferred(ctx, f, train_rows + slot * kMaxFwdGrid);
       }
-      if (d_out_val_loss) {
+      if (d_out_val_loss && !merged) {
         FwdArgs f = forward_args(d_val_indptr, d_val_indices, d_val_values, nullptr, n_val,
                                  d_w0, d_w, d_V, plan->k);
         f.y = d_val_y;

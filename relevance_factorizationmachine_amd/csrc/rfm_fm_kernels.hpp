@@ -118,6 +118,16 @@ struct FwdArgs {
   const double* pscore;
   const int32_t* row_ids;  // may be null: row t
   int64_t n_rows;
+  // SEG form (loss forwards of fit(), caller's CSR arrays): rows [0, n_rows_a) are rows row_ids[t]
+  // of the log above, rows [n_rows_a, n_rows) are rows t - n_rows_a of a SECOND log; each part
+  // has its own loss partials -- the train-loss and validation-loss forwards in one launch
+  int64_t n_rows_a;
+  const int64_t* indptr2;
+  const int32_t* indices2;
+  const double* values2;
+  const double* y2;
+  const double* pscore2;
+  double* loss_partial2;
   const double* w0;
   const double* w;
   const double* V;
@@ -163,10 +173,13 @@ struct FwdArgs {
 // LDS (dynamic): red[BLOCK] f64 | entry buffer [BLOCK/LPR][R*LPR+1] Entry | hot sums [H][k+2] f64
 // ELL (with REC): the records come as padded row blocks (a.ell).
 // DET (with REC): the hot-class sums in a fixed order (hot_fixed_order) instead of LDS atomics.
-template <int LPR, int VEC, int NC, int BLOCK, int R, bool REC, bool ELL = false, bool DET = false>
+// SEG (without REC, many-rows shape): two logs in one launch, see FwdArgs.
+template <int LPR, int VEC, int NC, int BLOCK, int R, bool REC, bool ELL = false, bool DET = false,
+          bool SEG = false>
 __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)) void fm_forward_kernel(
     FwdArgs a) {
   constexpr int GPB = BLOCK / LPR;  // lane groups per block
+  constexpr bool seg = SEG && !REC;
   extern __shared__ double dyn_lds[];
   const int tid = threadIdx.x;
   const int l = tid % LPR;
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
   uint8_t* hpos = reinterpret_cast<uint8_t*>(hbits + ((H * NW + 1) & ~1));
   const double w0 = a.w0[0];
   const int64_t last_row = a.n_rows - 1;
-  double loss_acc = 0.0, err_acc = 0.0;
+  double loss_acc = 0.0, loss_acc2 = 0.0, err_acc = 0.0;
   // many-rows shape, loss asked for, no hot class (whose sums would sit where the stages do)
   const bool stage_loss = BLOCK == kBigBlock && a.loss_partial != nullptr && H == 0;
   double* lstage = hot;  // [2][RT][3]
@@ -231,9 +244,17 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
       valid[i] = t[i] <= last_row;
       r[i] = int32_t(valid[i] ? t[i] : last_row);
     }
+    bool sb[R];  // SEG: the row belongs to the second log
+#pragma unroll
+    for (int i = 0; i < R; ++i) sb[i] = seg && (valid[i] ? t[i] : last_row) >= a.n_rows_a;
     if (a.row_ids) {  // uniform: the R loads stay in one block and overlap
 #pragma unroll
-      for (int i = 0; i < R; ++i) r[i] = a.row_ids[r[i]];
+      for (int i = 0; i < R; ++i) r[i] = a.row_ids[sb[i] ? 0 : r[i]];
+    }
+    if constexpr (seg) {
+#pragma unroll
+      for (int i = 0; i < R; ++i)
+        if (sb[i]) r[i] = int32_t((valid[i] ? t[i] : last_row) - a.n_rows_a);
     }
     // the workgroup's NEXT trip: its row ids now, and (below, under the hot pass) a touch of
     // its row blocks, so that the next trip's first two dependent loads find their lines
@@ -279,7 +300,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
         yy[i] = rec.y;
         pp[i] = rec.p;
       } else {
-        const int64_t b0 = a.indptr[r[i]], b1 = a.indptr[r[i] + 1];
+        const int64_t* ip = sb[i] ? a.indptr2 : a.indptr;
+        const int64_t b0 = ip[r[i]], b1 = ip[r[i] + 1];
         p0[i] = EntryOff(b0);
         len[i] = valid[i] ? int(b1 - b0) : 0;
         yy[i] = 0.0;
@@ -289,8 +311,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
     if (!REC && a.y) {
 #pragma unroll
       for (int i = 0; i < R; ++i) {
-        yy[i] = a.y[r[i]];
-        pp[i] = a.pscore[r[i]];
+        yy[i] = (sb[i] ? a.y2 : a.y)[r[i]];
+        pp[i] = (sb[i] ? a.pscore2 : a.pscore)[r[i]];
       }
     }
     int maxlen = len[0];
@@ -330,9 +352,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
         } else if (REC) {
           e[i] = a.ent[at];
         } else {
-          e[i].col = a.indices[at];
+          e[i].col = (sb[i] ? a.indices2 : a.indices)[at];
           e[i].slot = 0;
-          e[i].x = a.values[at];
+          e[i].x = (sb[i] ? a.values2 : a.values)[at];
         }
         // padding: the row's own last entry again with x = 0 (not some fixed column: a
         // non-finite row of V must reach only the rows that hold its column; an empty
@@ -426,6 +448,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
               st[0] = pred;
               st[1] = yy[i];
               st[2] = pp[i];
+            } else if (sb[i]) {
+              loss_acc2 += logloss_term(yy[i], pp[i], pred, a.eps);
             } else {
               loss_acc += logloss_term(yy[i], pp[i], pred, a.eps);
             }
@@ -443,7 +467,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
       __syncthreads();
       if (tid < RT) {
         const double* st = lstage + ((trip & 1) * RT + tid) * 3;
-        if (!(st[0] < 0.0)) loss_acc += logloss_term(st[1], st[2], st[0], a.eps);
+        if (!(st[0] < 0.0)) {  // (slot tid is row base + tid of the launch)
+          const double term = logloss_term(st[1], st[2], st[0], a.eps);
+          if (seg && base + tid >= a.n_rows_a)
+            loss_acc2 += term;
+          else
+            loss_acc += term;
+        }
       }
     }
     ++trip;
@@ -687,6 +717,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
   if (a.loss_partial) {
     const double s = block_sum<BLOCK>(loss_acc, red);
     if (tid == 0) a.loss_partial[blockIdx.x] = s;
+  }
+  if (seg && a.loss_partial2) {
+    const double s = block_sum<BLOCK>(loss_acc2, red);
+    if (tid == 0) a.loss_partial2[blockIdx.x] = s;
   }
 }
 

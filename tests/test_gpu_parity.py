@@ -997,7 +997,10 @@ def test_prepared_steps_experiment_gives_the_same_fit(rfm, monkeypatch, shape, k
     rt.clear_caches()
     np.testing.assert_array_equal(prep.V(), base.V())
     np.testing.assert_array_equal(prep.w(), base.w())
-    assert prep.w0(0) == base.w0(0) and tr1 == tr0 and va1 == va0
+    assert prep.w0(0) == base.w0(0)
+    # (the loss curves: the same forwards, but the default form may score the batch and the
+    # validation rows in one launch -- another partition of the same sum)
+    assert rel_err(tr1, tr0) < 1e-13 and rel_err(va1, va0) < 1e-13
 
 
 @pytest.mark.parametrize("k", [129, 130, 191, 257, 258, 300, 383, 384, 385, 400, 511])
@@ -1050,3 +1053,27 @@ def test_fm_fit_every_chunk_count(rfm, k):
     np.testing.assert_array_equal(cols, np.unique(Xb.indices))
     assert rel_err(rec[:, 1: k + 1], G_V[cols]) < TIGHT and rel_err(rec[:, k + 1], g_w[cols]) < TIGHT
     plan.close()
+
+
+@pytest.mark.parametrize("shape,k,batch", [("kuairec_small", 400, 2000), ("kuairec_small", 16, 2000), ("coat", 300, 500)])
+def test_merged_loss_forward_gives_the_same_losses(rfm, monkeypatch, shape, k, batch):
+    """The train-loss and validation-loss forwards of an iteration as ONE launch (the SEG form of the
+    forward: rows of two logs, two sets of loss partials; default for factor counts of several
+    chunks per lane, RFM_MERGE_LOSS=2 forces it, 0 forbids it): same parameters bit for bit, same
+    loss curves up to the order of the sums, both against the oracle."""
+    pkg, _lib, runtime, rt = rfm
+    sh = synth.SHAPES[shape]
+    train, val = synth.make_log(sh, "FM", "IPS", seed=0)
+    fits = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("RFM_MERGE_LOSS", mode)
+        m = pkg.FactorizationMachines(estimator="IPS", n_epochs=6, n_factors=k, lr=9e-6, batch_size=batch,
+                                      seed=12345, n_features=train["features"].shape[1])
+        m.deterministic = True
+        fits[mode] = (m, *m.fit(train, val))
+    monkeypatch.delenv("RFM_MERGE_LOSS")
+    (a, tra, vaa), (b, trb, vab) = fits["0"], fits["2"]
+    np.testing.assert_array_equal(a.V(), b.V())
+    assert rel_err(trb, tra) < 1e-13 and rel_err(vab, vaa) < 1e-13
+    ref = cpu_ref.fm_fit(train, val, n_epochs=6, n_factors=k, lr=9e-6, batch_size=batch, seed=12345)
+    assert rel_err(trb, ref["train_loss"]) < TIGHT and rel_err(vab, ref["val_loss"]) < TIGHT

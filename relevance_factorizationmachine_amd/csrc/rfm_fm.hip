@@ -364,7 +364,12 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
       if (chunked) {
         // one workgroup per (four tasks, chunk of 64 lanes x vec factors)
         const int n_chunks = ((k + s.vec - 1) / s.vec + 63) / 64;
-        const dim3 g2(grid, n_chunks);
+        c.n_chunks = n_chunks;
+        // chunks dealt to XCDs (see the kernel): every chunk gets at least 8 / n_chunks XCDs
+        static const bool xcd_on = env_int("RFM_XCD_CHUNKS", 1) != 0;
+        c.xcd_chunks = xcd_on && n_chunks <= 8 ? 1 : 0;
+        const int per_chunk = 8 / n_chunks;  // (the fewest XCDs a chunk gets)
+        const dim3 g2 = c.xcd_chunks ? dim3(8 * ((grid + per_chunk - 1) / per_chunk)) : dim3(grid, n_chunks);
         if (s.vec == 2 && prep)
           hipLaunchKernelGGL((fm_consume_kernel<64, 2, 1, true, true>), g2, dim3(kBlock), lds, ctx->stream, c);
         else if (s.vec == 2)

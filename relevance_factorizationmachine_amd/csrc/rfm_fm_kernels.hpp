@@ -886,6 +886,8 @@ struct ConsArgs {
   const double* hot_slab;
   int32_t n_slabs;
   const double* err_partial;  // [n_slabs] per-workgroup sums of the residual
+  int32_t n_chunks;           // CH form: chunks of 64 lanes x VEC factors
+  int32_t xcd_chunks;         // CH form: 1 = chunks dealt to XCDs (1-D grid), 0 = blockIdx.y
   // PREP form: the task's records and their number, the rows' residuals by batch position
   const PrepRec* prep_rec;    // [tasks][kPrepCap]
   const int32_t* prep_cnt;    // [tasks]
@@ -1030,7 +1032,23 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
   constexpr int PLANES = WinShape<LPR>::PLANES;
   constexpr int WIN = WinShape<LPR>::WIN;  // marked slots a group lists before it runs the chain
   constexpr int BATCH = CH ? RFM_CONS_CH_BATCH : 4;  // entries whose Q and V rows are in flight together
-  const int fb = CH ? int(blockIdx.y) * (LPR * VEC) : 0;  // first factor of this workgroup's chunk
+  // CH: which chunk and which group of tasks this workgroup takes.  Workgroups go to the eight
+  // XCDs round robin by their linear id, and every XCD has an L2 of its own: with the chunks
+  // dealt to XCDs (chunk c = the XCDs [8c / n, 8(c+1) / n)) an XCD only ever touches ITS slice of
+  // the Q rows and of V -- a quarter of them at k = 400 -- instead of all of both.
+  int bx = int(blockIdx.x), chunk = 0;
+  if (CH) {
+    if (a.xcd_chunks) {
+      const int xcd = bx & 7, slot = bx >> 3, nch = a.n_chunks;
+      chunk = xcd * nch / 8;
+      const int first = (chunk * 8 + nch - 1) / nch, next = ((chunk + 1) * 8 + nch - 1) / nch;
+      bx = slot * (next - first) + (xcd - first);
+      if (bx >= a.nb_tasks + a.n_hot + 1) return;  // (the grid is rounded up)
+    } else {
+      chunk = int(blockIdx.y);
+    }
+  }
+  const int fb = chunk * (LPR * VEC);  // first factor of this workgroup's chunk
   constexpr int TRIPS = kTaskTrips;        // bitmap words a lane loads (task_words <= TRIPS*LPR)
   // LDS: per group the list of marked slots and their parked records, then the head rows; or
   // (hot-column / w0 workgroups) reduction scratch
@@ -1040,9 +1058,9 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
   const int k = a.k;
   // the hot-column workgroups come last in the grid (measured: first, they delay the
   // tasks and the launch takes longer)
-  if (int(blockIdx.x) >= a.nb_tasks) {
-    if (CH && blockIdx.y != 0) return;
-    const int hb = int(blockIdx.x) - a.nb_tasks;
+  if (bx >= a.nb_tasks) {
+    if (CH && chunk != 0) return;
+    const int hb = bx - a.nb_tasks;
     double* tot = lds_raw + kBlock;
     if (hb < a.n_hot) {
       // a hot column: the forward workgroups' slabs, in block order; the column's row of V is
@@ -1075,7 +1093,7 @@ __global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
   const int lane = threadIdx.x % kWave;
   const int l = lane % LPR;
   const int gb = threadIdx.x / LPR;  // group in the workgroup
-  const int task = int(blockIdx.x) * GPB + gb;
+  const int task = bx * GPB + gb;
   const int W = a.task_words;
   const int32_t slot0 = task * W * 64;  // first slot of the task
   // first loads: the task's bitmap words (one per lane and trip) -- or, PREP, its records --

@@ -57,6 +57,11 @@ constexpr int kBigBlock = RFM_FWD_BIG_BLOCK;  // threads of the forward's many-r
 #ifndef RFM_FWD_SMALL_UNROLL
 #define RFM_FWD_SMALL_UNROLL 8
 #endif
+// ... of the one-row shape at two to four chunks of factors per lane (k = 300 / 400: an entry is
+// NC gathers per lane; the shape runs about two waves per SIMD, so registers are not the limit)
+#ifndef RFM_FWD_SMALL_WIDE_UNROLL
+#define RFM_FWD_SMALL_WIDE_UNROLL 2
+#endif
 
 // rows a lane group works on concurrently (independent load chains in flight)
 constexpr int rows_in_flight(int nc) { return nc == 1 ? RFM_FWD_ROWS : 1; }
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
       const int cnt = (maxlen - pb) < LPR ? (maxlen - pb) : LPR;
       // entries whose gathers are in flight together: the many-rows shape is at its register
       // budget with two (x R rows); the one-row shape has registers to spare
-#pragma unroll(BLOCK == kBigBlock || NC > 1 ? (NC == 1 && !DET && (ELL || !REC) ? (REC ? RFM_FWD_BIG_UNROLL : RFM_FWD_PLAIN_UNROLL) : 2) : RFM_FWD_SMALL_UNROLL)
+#pragma unroll(BLOCK == kBigBlock || NC > 1 ? (NC == 1 && !DET && (ELL || !REC) ? (REC ? RFM_FWD_BIG_UNROLL : RFM_FWD_PLAIN_UNROLL) : (BLOCK == kBigBlock || NC > 4 ? 2 : RFM_FWD_SMALL_WIDE_UNROLL)) : RFM_FWD_SMALL_UNROLL)
       for (int j = 0; j < cnt; ++j) {
         Entry ej[R];
         Pack<VEC> pv[R][NC];

@@ -15,8 +15,8 @@ else:
           " ".join(f"{n.split('_')[1]}={1e3*t:.1f}" for n, t in d["roofline"]["all_kernels_avg_ms"].items()))
 PY
 }
-for v in prep noprep; do
-  E=RFM_PREP=1; [ $v = noprep ] && E=RFM_PREP=0
+for v in prep prep2 noprep; do
+  E=RFM_PREP=1; [ $v = prep2 ] && E=RFM_PREP=2; [ $v = noprep ] && E=RFM_PREP=0
   env $E python bench.py --batch-size 2000 --steps 200 --warmup 20 --no-cpu-baseline --no-extra --no-pmc > "$OUT/b2000_$v.json" 2>> "$OUT/err.txt" && show "$OUT/b2000_$v.json" $v
   env $E python bench.py --published-only all > "$OUT/pub_$v.json" 2>> "$OUT/err.txt" && show "$OUT/pub_$v.json" $v
 done

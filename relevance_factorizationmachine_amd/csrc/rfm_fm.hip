@@ -289,14 +289,16 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
   unsigned long long* bits_other =
       plan->slot_bits.as<unsigned long long>() + (1 - parity) * plan->bits_words;
   f.slot_bits = bits;
-  if (prep) {  // rows at their batch position, nothing to mark
-    f.ent = nullptr;
-    f.rows = nullptr;
-    f.ell = reinterpret_cast<const char*>(prep->E);
-    f.ell_yp = prep->YP;
-    f.row_ids = nullptr;
+  if (prep) {  // nothing to mark ...
     f.slot_mark = nullptr;
     f.slot_bits = nullptr;
+    if (prep->E) {  // ... and the rows at their batch position
+      f.ent = nullptr;
+      f.rows = nullptr;
+      f.ell = reinterpret_cast<const char*>(prep->E);
+      f.ell_yp = prep->YP;
+      f.row_ids = nullptr;
+    }
   }
   f.n_hot = plan->n_hot;
   f.hot_rounds = plan->hot_rounds;
@@ -442,13 +444,14 @@ struct PrepRun {
   const int32_t* d_ids;
   int64_t batch, n_iters;
   int per_chunk = 0, n_chunks = 0;
-  bool on = false;
+  bool on = false, records_only = false;
 
   PrepRun(rfm_ctx* c, rfm_fm_plan* p, const int32_t* ids, int64_t b, int64_t n, bool allowed)
       : ctx(c), plan(p), d_ids(ids), batch(b), n_iters(n) {
     // (a short call -- an evaluator between iterations -- would pay the three launches of a
     // chunk for a handful of steps)
-    on = allowed && plan->prep_ok && n_iters >= 8 && plan->ell.p;
+    records_only = plan->prep_records_only;
+    on = allowed && plan->prep_ok && n_iters >= 8 && (records_only ? plan->rows.p != nullptr : plan->ell.p != nullptr);
     if (!on) return;
     per_chunk = plan->prep_iters;
     n_chunks = int((n_iters + per_chunk - 1) / per_chunk);
@@ -459,9 +462,11 @@ struct PrepRun {
   void enqueue(int c) {
     auto& ch = plan->prep[c % 2];
     const size_t cap_it = size_t(plan->prep_iters), nt = size_t(plan->n_tasks), mb = size_t(plan->max_batch);
-    if (!ch.E.p) {
-      ch.E.alloc(cap_it * mb * size_t(plan->ell_stride));
-      ch.YP.alloc(cap_it * mb * 16);
+    if (!ch.tmp.p) {
+      if (!records_only) {
+        ch.E.alloc(cap_it * mb * size_t(plan->ell_stride));
+        ch.YP.alloc(cap_it * mb * 16);
+      }
       ch.tmp.alloc(cap_it * nt * kPrepCap * sizeof(PrepTmp));
       ch.rec.alloc(cap_it * nt * kPrepCap * sizeof(PrepRec));
       ch.cnt.alloc(cap_it * nt * 4);
@@ -475,12 +480,21 @@ struct PrepRun {
     RFM_HIP_CHECK(hipMemsetAsync(ch.cnt.p, 0, size_t(n_it) * nt * 4, st));
     RFM_HIP_CHECK(hipMemsetAsync(ch.flags.p, 0, size_t(n_it) * 4, st));
     const Shape s = shape_for(plan->k);
-    const int64_t items = int64_t(n_it) * batch * s.lpr;
-    const int grid_a = int(std::max<int64_t>(1, std::min<int64_t>((items + kBlock - 1) / kBlock, int64_t(ctx->n_cu) * 32)));
-    hipLaunchKernelGGL(fm_prep_gather_kernel, dim3(grid_a), dim3(kBlock), 0, st, plan->ell.as<char>(),
-                       plan->ell_stride, plan->ell_yp.as<double2>(), s.lpr, d_ids + first * batch, batch,
-                       batch, n_it, int32_t(plan->task_words * 64), plan->n_tasks, ch.E.as<Entry>(),
-                       ch.YP.as<double2>(), ch.tmp.as<PrepTmp>(), ch.cnt.as<int32_t>());
+    if (records_only) {
+      const int64_t waves = int64_t(n_it) * batch;
+      const int grid_a = int(std::max<int64_t>(1, std::min<int64_t>((waves + 3) / 4, int64_t(ctx->n_cu) * 32)));
+      hipLaunchKernelGGL(fm_prep_bucket_kernel, dim3(grid_a), dim3(kBlock), 0, st, plan->rows.as<RowRec>(),
+                         plan->ent.as<Entry>(), d_ids + first * batch, batch, batch, n_it,
+                         int32_t(plan->task_words * 64), plan->n_tasks, ch.tmp.as<PrepTmp>(),
+                         ch.cnt.as<int32_t>());
+    } else {
+      const int64_t items = int64_t(n_it) * batch * s.lpr;
+      const int grid_a = int(std::max<int64_t>(1, std::min<int64_t>((items + kBlock - 1) / kBlock, int64_t(ctx->n_cu) * 32)));
+      hipLaunchKernelGGL(fm_prep_gather_kernel, dim3(grid_a), dim3(kBlock), 0, st, plan->ell.as<char>(),
+                         plan->ell_stride, plan->ell_yp.as<double2>(), s.lpr, d_ids + first * batch, batch,
+                         batch, n_it, int32_t(plan->task_words * 64), plan->n_tasks, ch.E.as<Entry>(),
+                         ch.YP.as<double2>(), ch.tmp.as<PrepTmp>(), ch.cnt.as<int32_t>());
+    }
     const int64_t buckets = int64_t(n_it) * plan->n_tasks;
     const int grid_b = int(std::max<int64_t>(1, std::min<int64_t>((buckets + 15) / 16, int64_t(ctx->n_cu) * 32)));
     hipLaunchKernelGGL(fm_prep_sort_kernel, dim3(grid_b), dim3(kBlock), 0, st, ch.tmp.as<PrepTmp>(),
@@ -500,8 +514,9 @@ struct PrepRun {
     if (j == 0) RFM_HIP_CHECK(hipEventSynchronize(ch.ready));  // its flags are on the host
     if (ch.h_flags[j]) return false;
     const size_t nt = size_t(plan->n_tasks);
-    v.E = reinterpret_cast<const Entry*>(ch.E.as<char>() + size_t(j) * size_t(batch) * size_t(plan->ell_stride));
-    v.YP = ch.YP.as<double2>() + size_t(j) * size_t(batch);
+    v.E = records_only ? nullptr
+                       : reinterpret_cast<const Entry*>(ch.E.as<char>() + size_t(j) * size_t(batch) * size_t(plan->ell_stride));
+    v.YP = records_only ? nullptr : ch.YP.as<double2>() + size_t(j) * size_t(batch);
     v.rec = ch.rec.as<PrepRec>() + size_t(j) * nt * kPrepCap;
     v.cnt = ch.cnt.as<int32_t>() + size_t(j) * nt;
     return true;
@@ -857,7 +872,7 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
     // 104.7 vs 111.6 us per iteration at B = 65 536).  RFM_MERGE_LOSS=0 / 2: never / always.
     const int merge_mode = env_int("RFM_MERGE_LOSS", 1);
     const bool merge_call = merge_mode != 0 && (merge_mode == 2 || shape_for(plan->k).nc > 1) &&
-                            d_out_train_loss && d_out_val_loss && !prepared.on &&
+                            d_out_train_loss && d_out_val_loss && (!prepared.on || prepared.records_only) &&
                             forward_geom(ctx, batch + n_val, shape_for(plan->k), false).block == kBigBlock;
     int64_t run_first = 0;
     for (int64_t it = 0; it < n_iters; ++it) {
@@ -892,10 +907,11 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
         FwdArgs f{};
         f.ent = plan->ent.as<Entry>();
         f.rows = plan->rows.as<RowRec>();
-        f.ell = is_prepared ? reinterpret_cast<const char*>(pv.E) : plan->ell.as<char>();
+        const bool rows_prepared = is_prepared && pv.E != nullptr;
+        f.ell = rows_prepared ? reinterpret_cast<const char*>(pv.E) : plan->ell.as<char>();
         f.ell_stride = plan->ell_stride;
-        f.ell_yp = is_prepared ? pv.YP : plan->ell_yp.as<double2>();
-        f.row_ids = is_prepared ? nullptr : ids;
+        f.ell_yp = rows_prepared ? pv.YP : plan->ell_yp.as<double2>();
+        f.row_ids = rows_prepared ? nullptr : ids;
         f.n_rows = batch;
         f.w0 = d_w0;
         f.w = d_w;

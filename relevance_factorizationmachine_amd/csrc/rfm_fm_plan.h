@@ -39,6 +39,7 @@ struct rfm_fm_plan {
   // batch-ordered row blocks E / YP and the tasks' records (tmp -> rec, cnt) of prep_iters
   // iterations, and the overflow flags of a chunk (device + pinned host copy + its event)
   bool prep_ok = false;       // the plan's layout allows prepared steps (padded row blocks, small batches)
+  bool prep_records_only = false;  // RFM_PREP=2: the tasks' records only, rows stay where they are
   int32_t prep_iters = 0;     // iterations per chunk
   int32_t n_tasks = 0;        // tasks of the plan (n_task_blocks x lane groups per workgroup)
   struct PrepChunk {

@@ -359,7 +359,8 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
   // profiles/r3i), plans for small batches keep the row blocks as the source
   // of PREPARED steps (rfm_fm_prep.hpp)
   const bool many_rows = forward_many_rows(ctx, max_batch, n_factors);
-  const bool want_prep = !many_rows && env_int("RFM_PREP", 0) != 0;
+  const int prep_mode = many_rows ? 0 : env_int("RFM_PREP", 0);
+  const bool want_prep = prep_mode == 1;
   if (nnz > 0 && max_len <= shp.lpr && (many_rows || want_prep) && env_int("RFM_NO_ELL", 0) == 0) {
     plan->ell_stride = int64_t(shp.lpr) * int64_t(sizeof(Entry));
     plan->ell.alloc(nr * size_t(plan->ell_stride));
@@ -380,6 +381,14 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
       plan->prep_iters = int32_t(std::min<size_t>(fit, 64));
       plan->prep_ok = plan->prep_iters >= 8;
     }
+  }
+  if (prep_mode == 2 && nnz > 0) {  // records only: nothing but the tasks' buckets per iteration
+    plan->n_tasks = int32_t(n_blocks * GPB);
+    const size_t per_iter = size_t(plan->n_tasks) * (size_t(kPrepCap) * 32 + 4);
+    const size_t fit = (size_t(env_int("RFM_PREP_MB", 384)) << 20) / std::max<size_t>(per_iter, 1);
+    plan->prep_iters = int32_t(std::min<size_t>(fit, 64));
+    plan->prep_ok = plan->prep_iters >= 8;
+    plan->prep_records_only = true;
   }
   upload(plan->tasks, tasks.data(), tasks.size() * sizeof(TaskRec), st);
   upload(plan->split, split.data(), split.size() * sizeof(SplitCol), st);

@@ -41,6 +41,30 @@ __global__ __launch_bounds__(kBlock) void fm_prep_gather_kernel(
   }
 }
 
+// The same buckets from the plan's plain records (RowRec / Entry), without copying the rows
+// (RFM_PREP=2: "records only" -- the forward keeps reading the plan's records by row id and
+// merely stops leaving marks): a wave per (iteration, batch position).
+__global__ __launch_bounds__(kBlock) void fm_prep_bucket_kernel(
+    const RowRec* rows, const Entry* ent, const int32_t* ids, int64_t ids_stride, int64_t batch,
+    int n_it, int32_t task_slots, int32_t n_tasks, PrepTmp* tmp, int32_t* cnt) {
+  const int lane = threadIdx.x % kWave;
+  const int64_t n_rows = int64_t(n_it) * batch;
+  for (int64_t row = (int64_t(blockIdx.x) * kBlock + threadIdx.x) / kWave; row < n_rows;
+       row += int64_t(gridDim.x) * (kBlock / kWave)) {
+    const int it = int(row / batch);
+    const int32_t t = int32_t(row % batch);
+    const RowRec rec = rows[ids[int64_t(it) * ids_stride + t]];
+    for (int64_t j = lane; j < rec.len; j += kWave) {
+      const Entry e = ent[rec.begin + j];
+      if (e.slot >= 0) {
+        const int64_t bucket = int64_t(it) * n_tasks + e.slot / task_slots;
+        const int pos = atomicAdd(&cnt[bucket], 1);
+        if (pos < kPrepCap) tmp[bucket * kPrepCap + pos] = PrepTmp{e.slot, t, e.x};
+      }
+    }
+  }
+}
+
 // one 16-lane group per (iteration, task); flags[it] = 1 when a bucket overflowed (that
 // iteration then takes the unprepared path)
 __global__ __launch_bounds__(kBlock) void fm_prep_sort_kernel(const PrepTmp* tmp, const int32_t* cnt,

@@ -991,16 +991,17 @@ def test_prepared_steps_experiment_gives_the_same_fit(rfm, monkeypatch, shape, k
     # several chunks in every case, and the hand-over between the two buffers)
     monkeypatch.setenv("RFM_PREP_MB", "48")
     base, (tr0, va0) = fit()
-    monkeypatch.setenv("RFM_PREP", "1")
-    prep, (tr1, va1) = fit()
-    monkeypatch.delenv("RFM_PREP")
-    rt.clear_caches()
-    np.testing.assert_array_equal(prep.V(), base.V())
-    np.testing.assert_array_equal(prep.w(), base.w())
-    assert prep.w0(0) == base.w0(0)
-    # (the loss curves: the same forwards, but the default form may score the batch and the
-    # validation rows in one launch -- another partition of the same sum)
-    assert rel_err(tr1, tr0) < 1e-13 and rel_err(va1, va0) < 1e-13
+    for mode in ("1", "2"):  # rows + records laid out ahead; records only
+        monkeypatch.setenv("RFM_PREP", mode)
+        prep, (tr1, va1) = fit()
+        monkeypatch.delenv("RFM_PREP")
+        rt.clear_caches()
+        np.testing.assert_array_equal(prep.V(), base.V())
+        np.testing.assert_array_equal(prep.w(), base.w())
+        assert prep.w0(0) == base.w0(0)
+        # (the loss curves: the same forwards, but the default form may score the batch and the
+        # validation rows in one launch -- another partition of the same sum)
+        assert rel_err(tr1, tr0) < 1e-13 and rel_err(va1, va0) < 1e-13
 
 
 @pytest.mark.parametrize("k", [129, 130, 191, 257, 258, 300, 383, 384, 385, 400, 511])

@@ -18,10 +18,9 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 # RFM_LIB_PATH: load another build of the same ABI (timing experiments under profiles/)
 LIB_PATH = os.environ.get("RFM_LIB_PATH") or os.path.join(PKG_DIR, "librfm_hip.so")
 SOURCES = ["rfm_capi.hip", "rfm_fm.hip", "rfm_fm_plan.hip", "rfm_mf.hip", "rfm_eval.hip", "rfm_csr.hip", "rfm_host.cpp", "rfm_comm.cpp"]
-HEADERS = [os.path.join(CSRC, "rfm_common.h"), os.path.join(CSRC, "rfm_fm_kernels.hpp"),
-           os.path.join(CSRC, "rfm_fm_rows.hpp"), os.path.join(CSRC, "rfm_fm_plan.h"),
-           os.path.join(CSRC, "rfm_fm_records.h"), os.path.join(CSRC, "rfm_device_utils.hpp"),
-           os.path.join(os.path.dirname(PKG_DIR), "include", "rfm_hip.h")]
+# every header under csrc/ (a change of any of them rebuilds every object) + the C ABI
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))) + [
+    os.path.join(os.path.dirname(PKG_DIR), "include", "rfm_hip.h")]
 
 RFM_OK, RFM_ERR_BAD_ARG, RFM_ERR_HIP, RFM_ERR_NO_DEVICE, RFM_ERR_INTERNAL = range(5)
 

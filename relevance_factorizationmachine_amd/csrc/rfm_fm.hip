@@ -32,6 +32,7 @@
 #include "rfm_fm_plan.h"
 #include "rfm_fm_prep.hpp"
 #include "rfm_fm_rows.hpp"
+#include "rfm_fm_sliced.hpp"
 
 static_assert(RFM_MAX_FACTORS <= 1024, "fm_finalize_kernel's LDS totals hold 1024+2 values");
 
@@ -200,6 +201,53 @@ int forward_loss_deferred(rfm_ctx* ctx, FwdArgs a, double* partial_row) {
   a.loss_partial = partial_row;
   launch_forward(ctx, a, geom);
   return geom.grid;
+}
+
+// Sliced loss forward (rfm_fm_sliced.hpp) over `rows` rows: workgroups per slice (one
+// workgroup per CU, a multiple of the XCDs a slice is dealt to), rows per workgroup and per
+// staged chunk, LDS.  ok = false: the plan has no slices, or the rows are too few to pay for
+// every workgroup's copy of the cached columns (RFM_SLICED_MIN_ROWS, default 4 096;
+// RFM_SLICED_LOSS=0: never).
+struct SlicedGeom {
+  bool ok = false;
+  int grid = 0, rows_per_wg = 0;
+  size_t lds = 0;
+};
+SlicedGeom sliced_geom(const rfm_ctx* ctx, const rfm_fm_plan* plan, int64_t rows) {
+  SlicedGeom g;
+  if (plan->sl_ns <= 0 || env_int("RFM_SLICED_LOSS", 1) == 0) return g;
+  if (rows < std::max(1, env_int("RFM_SLICED_MIN_ROWS", 4096))) return g;
+  const int xs = 8 / plan->sl_ns;
+  int wps = std::max(xs, ctx->n_cu / plan->sl_ns / xs * xs);
+  // (few rows: fewer, fuller workgroups -- each fills its own copy of the cached columns)
+  const int64_t min_rows = kSlWaves * 4;
+  while (wps > xs && rows / wps < min_rows) wps -= xs;
+  g.rows_per_wg = int(std::min<int64_t>((rows + wps - 1) / wps, INT32_MAX));
+  g.lds = sliced_lds_bytes(plan->sl_n_cached, plan->sl_sw);
+  if (g.lds > size_t(kSlicedLds)) return g;
+  g.grid = 8 * (wps / xs);
+  g.ok = true;
+  return g;
+}
+
+void launch_sliced(rfm_ctx* ctx, const rfm_fm_plan* plan, const SlicedGeom& g, SlicedArgs a) {
+  a.k = plan->k;
+  a.ns = plan->sl_ns;
+  a.sw = plan->sl_sw;
+  a.n_cached = plan->sl_n_cached;
+  a.cached_cols = plan->sl_cols.as<int32_t>();
+  a.cached_rank = plan->sl_rank.as<int32_t>();
+  a.ml_log2 = plan->sl_ml_log2;
+  a.rows_per_wg = g.rows_per_wg;
+  static std::atomic<size_t> lds_allowed[kMaxDevices];
+  const int dev = ctx->device >= 0 && ctx->device < kMaxDevices ? ctx->device : -1;
+  if (g.lds > (64u << 10) && (dev < 0 || g.lds > lds_allowed[dev].load(std::memory_order_relaxed))) {
+    RFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fm_logit_slices_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(g.lds)));
+    if (dev >= 0) lds_allowed[dev].store(g.lds, std::memory_order_relaxed);
+  }
+  hipLaunchKernelGGL(fm_logit_slices_kernel, dim3(g.grid), dim3(kSlBlock), g.lds, ctx->stream, a);
+  RFM_HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace rfm
@@ -848,8 +896,46 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
     double* train_rows = plan->loss_rows.as<double>();
     double* val_rows = train_rows + kRun * kMaxFwdGrid;
     int train_parts = 0, val_parts = 0;
+    // factor counts of several chunks per lane: the loss forwards sliced by factors, ONE launch
+    // per iteration that leaves partial logits; the scores and logarithms of a whole run of
+    // iterations are then computed together (rfm_fm_sliced.hpp)
+    const int64_t sl_a = d_out_train_loss ? batch : 0, sl_b = d_out_val_loss ? n_val : 0;
+    const SlicedGeom sliced = sliced_geom(ctx, plan, sl_a + sl_b);
+    int64_t run_len = kRun;
+    const int64_t z_per_iter = int64_t(plan->sl_ns) * (sl_a + sl_b);
+    if (sliced.ok) {
+      run_len = std::max<int64_t>(1, std::min<int64_t>(kRun, (int64_t(256) << 20) / (z_per_iter * 8)));
+      run_len = std::min(run_len, n_iters);
+      plan->sl_z.ensure(size_t(run_len) * size_t(z_per_iter) * 8);
+      // (the validation log is only known here: translated once per call)
+      if (sl_b > 0) sliced_translate(ctx, plan, d_val_indptr, d_val_indices, d_val_values, sl_b, plan->sl_val);
+    }
+#ifdef RFM_SLICED_STAMPS
+    DevBuf stamps;
+    if (sliced.ok && env_int("RFM_SLICED_STAMPS", 0)) {
+      stamps.alloc(size_t(sliced.grid) * kSlWaves * 8 * 8);
+      RFM_HIP_CHECK(hipMemsetAsync(stamps.p, 0, stamps.bytes, ctx->stream));
+    }
+#endif
     const auto finish = [&](int64_t first, int64_t count) {
       if (count <= 0) return;
+      if (sliced.ok) {
+        const auto shares = [&](int64_t rows) { return int(std::min<int64_t>(64, (rows + kBlock - 1) / kBlock)); };
+        if (sl_a > 0) {
+          train_parts = shares(sl_a);
+          hipLaunchKernelGGL(loss_from_slices_kernel, dim3(train_parts, int(count)), dim3(kBlock), 0,
+                             ctx->stream, plan->sl_z.as<double>(), z_per_iter, plan->sl_ns,
+                             sl_a + sl_b, int64_t(0), sl_a, d_ids + first * batch, batch, d_y,
+                             d_pscore, eps, train_rows, int64_t(kMaxFwdGrid));
+        }
+        if (sl_b > 0) {
+          val_parts = shares(sl_b);
+          hipLaunchKernelGGL(loss_from_slices_kernel, dim3(val_parts, int(count)), dim3(kBlock), 0,
+                             ctx->stream, plan->sl_z.as<double>(), z_per_iter, plan->sl_ns,
+                             sl_a + sl_b, sl_a, sl_b, static_cast<const int32_t*>(nullptr),
+                             int64_t(0), d_val_y, d_val_pscore, eps, val_rows, int64_t(kMaxFwdGrid));
+        }
+      }
       if (d_out_train_loss)
         hipLaunchKernelGGL(loss_finish_many_kernel, dim3(int(count)), dim3(kBlock), 0, ctx->stream,
                            train_rows, int64_t(kMaxFwdGrid), train_parts, batch,
@@ -885,7 +971,30 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
       // both losses asked for: ONE launch over the batch's rows of the training log and the
       // validation log (RFM_MERGE_LOSS=0: two launches)
       bool merged = false;
-      if (merge_call) {
+      if (sliced.ok) {
+        SlicedArgs f{};
+        f.tr_a = plan->sl_train.as<SlEnt>();
+        f.tr_b = plan->sl_val.as<SlEnt>();
+        f.pad = plan->sl_pad.as<SlEnt>();
+        f.indptr_a = d_indptr;
+        f.indices_a = d_indices;
+        f.values_a = d_values;
+        f.row_ids = ids;
+        f.n_a = sl_a;
+        f.indptr_b = d_val_indptr;
+        f.indices_b = d_val_indices;
+        f.values_b = d_val_values;
+        f.n_b = sl_b;
+        f.w0 = d_w0;
+        f.w = d_w;
+        f.V = d_V;
+        f.zpart = plan->sl_z.as<double>() + slot * z_per_iter;
+#ifdef RFM_SLICED_STAMPS
+        f.stamps = static_cast<long long*>(stamps.p);
+#endif
+        launch_sliced(ctx, plan, sliced, f);
+        merged = true;
+      } else if (merge_call) {
         FwdArgs f = forward_args(d_indptr, d_indices, d_values, ids, batch + n_val, d_w0, d_w, d_V, plan->k);
         f.n_rows_a = batch;
         f.y = d_y;
@@ -928,14 +1037,32 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
         f.eps = eps;
         val_parts = forward_loss_deferred(ctx, f, val_rows + slot * kMaxFwdGrid);
       }
-      if (slot + 1 == kRun) {
-        finish(run_first, kRun);
+      if (slot + 1 == run_len) {
+        finish(run_first, run_len);
         run_first = it + 1;
       }
       prepared.done(it);
     }
     finish(run_first, n_iters - run_first);
     capture.replay(n_iters);
+#ifdef RFM_SLICED_STAMPS
+    if (sliced.ok && stamps.p) {  // the LAST iteration's clock readings, averaged over the workgroups
+      std::vector<long long> h(size_t(sliced.grid) * kSlWaves * 8);
+      RFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      RFM_HIP_CHECK(hipMemcpy(h.data(), stamps.p, h.size() * 8, hipMemcpyDeviceToHost));
+      for (int wv : {0, kSlWaves - 1}) {
+        double d[7] = {0}, n = 0;
+        for (int b = 0; b < sliced.grid; ++b) {
+          const long long* t = &h[(size_t(b) * kSlWaves + wv) * 8];
+          if (!t[0] || !t[6]) continue;
+          for (int i = 1; i < 7; ++i) d[i] += double(t[i] - t[0]);
+          n += 1;
+        }
+        fprintf(stderr, "[sliced stamps] wave %d over %.0f workgroups (clocks since entry): fill issued+summed %.0f, barrier %.0f, prologue %.0f, row 1 %.0f, row 8 %.0f, end %.0f\n",
+                wv, n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, d[5] / n, d[6] / n);
+      }
+    }
+#endif
   });
 }
 

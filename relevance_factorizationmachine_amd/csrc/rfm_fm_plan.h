@@ -25,6 +25,15 @@ struct rfm_fm_plan {
   rfm::DevBuf ent, rows, slot_t, slot_bits, slots, tasks, split, parts, Q, err, hot_cols, hot_slab,
       err_partial;
   rfm::DevBuf loss_rows;  // rfm_fm_train: per-workgroup loss partials of a run of iterations
+  // sliced loss forwards of rfm_fm_train (rfm_fm_sliced.hpp; k > 128 and even): slices of the
+  // factors, factors per slice, records per translated row (log2), and the log's most frequent columns --
+  // the ones a workgroup keeps in LDS -- as a list and as a rank per column
+  int32_t sl_ns = 0, sl_sw = 0, sl_ml_log2 = 4, sl_n_cached = 0;
+  rfm::DevBuf sl_cols, sl_rank;
+  rfm::DevBuf sl_train;  // the training log translated (rows of 2^sl_ml_log2 SlEnt records)
+  rfm::DevBuf sl_pad;    // one padding record
+  rfm::DevBuf sl_val;    // ... the validation log of the current rfm_fm_train call
+  rfm::DevBuf sl_z;      // partial logits [iterations of a run][slices][rows]
   std::vector<int32_t> h_hot_cols;  // host copy of hot_cols (rfm_fm_plan_hot_columns)
   // touched-row gradients (rfm_fm_grad_rows), allocated on first use: the gradient table
   // [G_V | g_w | g_w0] indexed by column, never cleared; touch[col] == touch_seq marks the
@@ -81,6 +90,11 @@ inline int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
 }
+
+// a log translated for the sliced loss forward of `plan` (rfm_fm_sliced.hpp), on ctx's stream
+// (defined in rfm_fm_plan.hip)
+void sliced_translate(rfm_ctx* ctx, const rfm_fm_plan* plan, const int64_t* d_indptr,
+                      const int32_t* d_indices, const double* d_values, int64_t n_rows, DevBuf& out);
 
 // workgroups the training forward launches for `rows` batch rows (defined in rfm_fm.hip)
 int forward_grid(const rfm_ctx* ctx, int64_t rows, int n_factors);

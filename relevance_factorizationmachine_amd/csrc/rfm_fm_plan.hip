@@ -115,6 +115,51 @@ __global__ __launch_bounds__(kBlock) void plan_ell_kernel(const RowRec* rows, co
   }
 }
 
+// A log in the form the sliced loss forward reads (rfm_fm_sliced.hpp): 2^mll records per row,
+// cached columns first.  A row belongs to 2^mll consecutive lanes of one wavefront (entry e
+// in lane e); a record's place is the count of the records of its kind before it (ballots).
+__global__ __launch_bounds__(kBlock) void sl_translate_kernel(const int64_t* indptr, const int32_t* indices,
+                                                            const double* values, int64_t n_rows,
+                                                            const int32_t* rank, int mll, int n_cached,
+                                                            int row_bytes, SlEnt* out) {
+  const int ML = 1 << mll;
+  const int64_t total = n_rows << mll;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int shift = lane & ~(ML - 1);  // first lane of this row's group
+  const unsigned long long group = ML == 64 ? ~0ull : ((1ull << ML) - 1ull);
+  const int zoff = n_cached * row_bytes;
+  for (int64_t s0 = int64_t(blockIdx.x) * kBlock; s0 < total; s0 += int64_t(gridDim.x) * kBlock) {
+    const int64_t s = s0 + threadIdx.x;  // (total is a multiple of 2^mll: a group is whole or absent)
+    const bool live = s < total;
+    const int64_t r = live ? s >> mll : 0;
+    const int e = int(s & (ML - 1));
+    const int64_t b0 = indptr[r], len = indptr[r + 1] - b0;
+    SlEnt o{zoff, kSlPad, 0.0};
+    int kind = 2;  // 0 cached, 1 not cached, 2 padding
+    if (live && len > ML) {
+      if (e == 0) o.col = kSlLong;
+    } else if (live && e < len) {
+      const int32_t col = indices[b0 + e];
+      const int32_t rk = rank[col];
+      kind = rk >= 0 ? 0 : 1;
+      if (rk >= 0) o.off = rk * row_bytes;
+      o.col = col;
+      o.x = values[b0 + e];
+    }
+    const unsigned long long mc = (__ballot(kind == 0) >> shift) & group;
+    const unsigned long long mu = (__ballot(kind == 1) >> shift) & group;
+    const unsigned long long below = (1ull << e) - 1ull;
+    int pos;
+    if (kind == 0)
+      pos = __popcll(mc & below);
+    else if (kind == 1)
+      pos = __popcll(mc) + __popcll(mu & below);
+    else
+      pos = __popcll(mc) + __popcll(mu) + __popcll(~(mc | mu) & group & below);
+    if (live) out[(r << mll) + pos] = o;
+  }
+}
+
 void upload(DevBuf& dst, const void* src, size_t bytes, hipStream_t stream) {
   dst.alloc(bytes);
   if (bytes) RFM_HIP_CHECK(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, stream));
@@ -390,6 +435,46 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
     plan->prep_ok = plan->prep_iters >= 8;
     plan->prep_records_only = true;
   }
+  // sliced loss forwards (rfm_fm_sliced.hpp): factor counts of several chunks per lane, even
+  // (16-byte loads).  Slices: the power of two that covers k in 256-factor pieces (so that the
+  // slices divide the eight XCDs), evenly wide.  Cached columns: at least one row in 64 holds
+  // them, most frequent first, as many as the LDS left beside the staged rows takes.
+  std::vector<int32_t> sl_cols, sl_rank;
+  if (shp.nc > 1 && n_factors % 2 == 0 && n_factors <= 1024 && nnz > 0) {
+    int ns = 1;  // (a wavefront covers 256 factors of a row: four per lane)
+    while (ns * 256 < n_factors) ns *= 2;
+    const int sw = ((n_factors + ns - 1) / ns + 1) & ~1;
+    // (... and while the translated training log stays below 4 GiB)
+    if (ns <= 8 && int64_t(ns - 1) * sw < n_factors && (n_rows << 6) * 16 <= (int64_t(4) << 30)) {
+      plan->sl_ns = ns;
+      plan->sl_sw = sw;
+      int mll = 4;
+      while ((int64_t(1) << mll) < max_len && mll < 6) ++mll;
+      plan->sl_ml_log2 = mll;
+      for (size_t c = 0; c < nf; ++c)
+        if (len(c) * 64 >= n_rows) sl_cols.push_back(int32_t(c));
+      std::stable_sort(sl_cols.begin(), sl_cols.end(),
+                       [&](int32_t x, int32_t y) { return len(size_t(x)) > len(size_t(y)); });
+      const size_t cap = size_t(kSlicedLds - 2048) / size_t(sliced_row_bytes(sw)) - 1;  // (+ the zero row)
+      if (sl_cols.size() > cap) sl_cols.resize(cap);
+      sl_rank.assign(nf, -1);
+      for (size_t h = 0; h < sl_cols.size(); ++h) sl_rank[size_t(sl_cols[h])] = int32_t(h);
+      plan->sl_n_cached = int32_t(sl_cols.size());
+      if (sl_cols.empty())
+        plan->sl_cols.alloc(4);
+      else
+        upload(plan->sl_cols, sl_cols.data(), sl_cols.size() * 4, st);
+      upload(plan->sl_rank, sl_rank.data(), nf * 4, st);
+      const SlEnt pad_record{plan->sl_n_cached * sliced_row_bytes(sw), kSlPad, 0.0};
+      upload(plan->sl_pad, &pad_record, sizeof(SlEnt), st);
+      // the training log in its translated form (rows of 2^mll records)
+      plan->sl_train.alloc((nr << mll) * sizeof(SlEnt));
+      hipLaunchKernelGGL(sl_translate_kernel, dim3(grid_for(ctx, n_rows << mll)), dim3(kBlock), 0, st,
+                         d_indptr, d_indices, d_values, n_rows, plan->sl_rank.as<int32_t>(), mll,
+                         plan->sl_n_cached, sliced_row_bytes(sw), plan->sl_train.as<SlEnt>());
+      RFM_HIP_CHECK(hipGetLastError());
+    }
+  }
   upload(plan->tasks, tasks.data(), tasks.size() * sizeof(TaskRec), st);
   upload(plan->split, split.data(), split.size() * sizeof(SplitCol), st);
   upload(plan->hot_cols, hot_cols.data(), hot_cols.size() * 4, st);
@@ -415,6 +500,19 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
 }
 
 }  // namespace
+
+void sliced_translate(rfm_ctx* ctx, const rfm_fm_plan* plan, const int64_t* d_indptr,
+                      const int32_t* d_indices, const double* d_values, int64_t n_rows, DevBuf& out) {
+  const int mll = plan->sl_ml_log2;
+  out.ensure((size_t(std::max<int64_t>(n_rows, 1)) << mll) * sizeof(SlEnt));
+  if (n_rows <= 0) return;
+  hipLaunchKernelGGL(sl_translate_kernel, dim3(grid_for(ctx, n_rows << mll)), dim3(kBlock), 0,
+                     ctx->stream, d_indptr, d_indices, d_values, n_rows,
+                     plan->sl_rank.as<int32_t>(), mll, plan->sl_n_cached,
+                     sliced_row_bytes(plan->sl_sw), out.as<SlEnt>());
+  RFM_HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace rfm
 
 using namespace rfm;

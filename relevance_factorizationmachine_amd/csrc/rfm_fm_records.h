@@ -71,4 +71,19 @@ struct PrepRec {  // in slot order
 };
 
 
+// Sliced loss forwards (rfm_fm_sliced.hpp): LDS of a workgroup (the cached columns' slices)
+constexpr int kSlicedLds = 160 << 10;
+struct SlEnt {   // one entry of a translated log, 16 B.  A row's records: the cached columns'
+                 // entries first (in row order), then the others, then padding
+  int32_t off;   // byte offset of the column's slice in the workgroup's LDS copy; the ZERO row's
+                 // (n_cached rows in) for a column that is not cached and for padding
+  int32_t col;   // the column; kSlPad: no entry; kSlLong (record 0): the row is longer than the
+                 // records of a row -- read it from the CSR arrays
+  double x;
+};
+constexpr int32_t kSlPad = -1;
+constexpr int32_t kSlLong = -2;
+// bytes of a cached column's LDS row: its slice, its squared norm, 8 bytes of padding
+constexpr int sliced_row_bytes(int sw) { return sw * 8 + 16; }
+
 }  // namespace rfm

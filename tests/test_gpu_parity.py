@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 import pytest
-from scipy.sparse import csr_matrix, random as sprandom
+from scipy.sparse import csr_matrix, random as sprandom, vstack
 
 from conftest import assert_elementwise, load_golden, rel_err
 from oracle import cpu_ref
@@ -1066,6 +1066,7 @@ def test_merged_loss_forward_gives_the_same_losses(rfm, monkeypatch, shape, k, b
     sh = synth.SHAPES[shape]
     train, val = synth.make_log(sh, "FM", "IPS", seed=0)
     fits = {}
+    monkeypatch.setenv("RFM_SLICED_LOSS", "0")  # (the sliced loss forward would take k = 400 over)
     for mode in ("0", "2"):
         monkeypatch.setenv("RFM_MERGE_LOSS", mode)
         m = pkg.FactorizationMachines(estimator="IPS", n_epochs=6, n_factors=k, lr=9e-6, batch_size=batch,
@@ -1078,3 +1079,106 @@ def test_merged_loss_forward_gives_the_same_losses(rfm, monkeypatch, shape, k, b
     assert rel_err(trb, tra) < 1e-13 and rel_err(vab, vaa) < 1e-13
     ref = cpu_ref.fm_fit(train, val, n_epochs=6, n_factors=k, lr=9e-6, batch_size=batch, seed=12345)
     assert rel_err(trb, ref["train_loss"]) < TIGHT and rel_err(vab, ref["val_loss"]) < TIGHT
+
+
+@pytest.mark.parametrize("k,n_cols,density,val_kind", [
+    (130, 300, 0.03, "same"), (192, 300, 0.03, "long"), (258, 120, 0.15, "same"), (300, 300, 0.03, "mixed"),
+    (400, 300, 0.03, "same"), (400, 40, 0.9, "long"), (514, 300, 0.03, "empty_rows"), (1022, 200, 0.05, "mixed"),
+    (1024, 200, 0.05, "same")])
+def test_sliced_loss_forward_gives_the_same_losses(rfm, monkeypatch, k, n_cols, density, val_kind):
+    """The loss forwards of fit() sliced by factors (rfm_fm_sliced.hpp: every even k > 128, taken when
+    the batch and the validation log together have enough rows; RFM_SLICED_MIN_ROWS=1 forces it,
+    RFM_SLICED_LOSS=0 forbids it): same parameters bit for bit, loss curves equal to the plain
+    forwards' up to the order of the sums, both against the oracle.  Slices of 2, 4 and 8 pieces with a
+    narrower last slice; staged rows of 16 / 32 / 64 entries; validation rows LONGER than the staging
+    stride derived from the training log (read straight from the log), empty rows, rows of cached
+    columns only and of uncached columns only; twice in a row (the second fit finds a warm plan)."""
+    pkg = rfm[0]
+    rng = np.random.default_rng(7 * k + n_cols)
+    train = _random_log(rng, 3000, n_cols, density, 4)
+    if val_kind == "same":
+        val = _random_log(rng, 700, n_cols, density, 4)
+    elif val_kind == "long":  # every validation row longer than any training row
+        val = _random_log(rng, 300, n_cols, min(1.0, density * 6 + 0.3), 4)
+    else:
+        a = _random_log(rng, 400, n_cols, density, 4)
+        b = _random_log(rng, 200, n_cols, min(1.0, density * 8 + 0.3), 0)
+        X = vstack([a["features"], b["features"]]).tolil()
+        if val_kind == "empty_rows":
+            X[0, :] = 0
+            X[17, :] = 0
+            X[599, :] = 0
+        X[3, 4:] = 0   # only columns that are in every training row
+        X[5, :4] = 0   # none of them
+        X = X.tocsr()
+        X.eliminate_zeros()
+        X.sort_indices()
+        val = {"features": X, "labels": np.concatenate([a["labels"], b["labels"]]),
+               "pscores": np.concatenate([a["pscores"], b["pscores"]])}
+    lr, batch, its = 2e-6, 1000, 4
+    fits = {}
+    for mode in ("plain", "sliced"):
+        monkeypatch.setenv("RFM_SLICED_LOSS", "0" if mode == "plain" else "1")
+        monkeypatch.setenv("RFM_SLICED_MIN_ROWS", "1")
+        m = _fm(pkg, n_factors=k, n_features=n_cols, lr=lr, batch_size=batch, n_epochs=its, seed=5)
+        first = m.fit(train, val)
+        m2 = _fm(pkg, n_factors=k, n_features=n_cols, lr=lr, batch_size=batch, n_epochs=its, seed=5)
+        again = m2.fit(train, val)
+        np.testing.assert_array_equal(np.asarray(first), np.asarray(again))
+        fits[mode] = (m, *first)
+    monkeypatch.delenv("RFM_SLICED_LOSS")
+    monkeypatch.delenv("RFM_SLICED_MIN_ROWS")
+    (a, tra, vaa), (b, trb, vab) = fits["plain"], fits["sliced"]
+    np.testing.assert_array_equal(a.V(), b.V())
+    assert rel_err(trb, tra) < 1e-12 and rel_err(vab, vaa) < 1e-12
+    ref = cpu_ref.fm_fit(train, val, n_epochs=its, n_factors=k, lr=lr, batch_size=batch, seed=5)
+    assert rel_err(trb, ref["train_loss"]) < TIGHT and rel_err(vab, ref["val_loss"]) < TIGHT
+    assert_elementwise(trb, ref["train_loss"], what="train loss")
+    assert_elementwise(vab, ref["val_loss"], what="validation loss")
+
+
+@pytest.mark.parametrize("bad_col,holders", [(10, 100), (150, 5)])
+def test_sliced_loss_forward_keeps_a_non_finite_row_to_itself(rfm, monkeypatch, bad_col, holders):
+    """A non-finite row of V reaches exactly the rows that hold its column: a validation log without
+    the column keeps a finite loss, equal to the plain forward's, and one with it turns NaN -- with
+    the column among the cached ones (100 training rows hold it) and not (5 do).  The holders are
+    training rows that no batch of the fit samples, so the step never spreads the NaN."""
+    pkg, _lib, runtime, rt = rfm
+    rng = np.random.default_rng(3)
+    train = _random_log(rng, 2000, 200, 0.04, 3)
+    val = _random_log(rng, 500, 200, 0.04, 3)
+    batch, its = 500, 3
+    sampled = np.unique(runtime.sample_batches(2000, batch, 0, its))
+    free = np.setdiff1d(np.arange(2000), sampled)
+    assert free.size >= holders
+    Xt = train["features"].tolil()
+    Xt[:, bad_col] = 0
+    Xt[free[:holders], bad_col] = 1.5
+    train["features"] = Xt.tocsr()
+    train["features"].eliminate_zeros()
+    Xv = val["features"].tolil()
+    Xv[:, bad_col] = 0
+    without = dict(val, features=Xv.tocsr())
+    without["features"].eliminate_zeros()
+    Xv[::7, bad_col] = 0.5
+    with_col = dict(val, features=Xv.tocsr())
+    monkeypatch.setenv("RFM_SLICED_MIN_ROWS", "1")
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RFM_SLICED_LOSS", mode)
+        for name, v in (("without", without), ("with", with_col)):
+            m = _fm(pkg, n_factors=300, n_features=200, lr=1e-6, batch_size=batch, n_epochs=its, seed=5)
+            V = m.V()
+            V[bad_col, 7] = np.inf
+            V[bad_col, 290] = np.nan
+            m.V.set(V)
+            out[mode, name] = m.fit(train, v)
+    monkeypatch.delenv("RFM_SLICED_LOSS")
+    monkeypatch.delenv("RFM_SLICED_MIN_ROWS")
+    for name in ("without", "with"):
+        (tr0, va0), (tr1, va1) = out["0", name], out["1", name]
+        assert np.isfinite(tr0).all() and np.isfinite(tr1).all() and rel_err(tr1, tr0) < 1e-12
+        if name == "without":
+            assert np.isfinite(va1).all() and rel_err(va1, va0) < 1e-12
+        else:
+            assert np.isnan(va0).all() and np.isnan(va1).all()

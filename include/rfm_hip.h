@@ -169,6 +169,10 @@ int32_t rfm_fm_plan_info(const rfm_fm_plan* plan, int64_t* h_out8);
  * row + entry records; [1]=bytes of a row block (0 if none); [2]=lanes per row of this
  * factor count; [3]=entries of the longest row */
 int32_t rfm_fm_plan_layout(const rfm_fm_plan* plan, int32_t* h_out4);
+/* the sliced loss forwards of rfm_fm_train (even factor counts above 128): h_out4[0]=slices of
+ * the factors (0: this plan has none), [1]=factors per slice, [2]=columns whose slice a workgroup
+ * keeps in LDS, [3]=records per row of the translated logs */
+int32_t rfm_fm_plan_sliced(const rfm_fm_plan* plan, int32_t* h_out4);
 /* the hot columns (ascending), h_out[0 .. info[2]); capacity = room in h_out */
 int32_t rfm_fm_plan_hot_columns(const rfm_fm_plan* plan, int32_t* h_out, int32_t capacity);
 
@@ -254,7 +258,11 @@ int32_t rfm_fm_set_rows(rfm_ctx* ctx, const double* d_rows, int64_t n_rows,
  * loss of the SAME batch with the new parameters, then the validation loss.
  * d_out_train_loss / d_out_val_loss receive one value per iteration (either
  * may be NULL to skip that forward).  Everything is enqueued on the ctx
- * stream; nothing synchronises.  (Environment, experiments only: RFM_PREP=1 at plan creation
+ * stream; nothing synchronises.  For even factor counts above 128 (every published run of the
+ * reference) the two loss forwards are ONE launch sliced by factors that keeps the log's frequent
+ * columns in LDS, once the batch and the validation log together have RFM_SLICED_MIN_ROWS rows
+ * (default 4 096; RFM_SLICED_LOSS=0: never) -- same losses up to the order of the sums.
+ * (Environment, experiments only: RFM_PREP=1 at plan creation
  * makes calls of 8 or more iterations lay their batches out ahead of the loop -- same results bit
  * for bit, one wait on an event per chunk of iterations; RFM_TRAIN_GRAPH=1 replays the call's
  * launches as one hipGraph.) */

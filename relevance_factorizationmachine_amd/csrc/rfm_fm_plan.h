@@ -67,7 +67,7 @@ struct rfm_fm_plan {
   size_t device_bytes() const {
     return ell.bytes + ell_yp.bytes + ent.bytes + rows.bytes + slot_t.bytes + slot_bits.bytes + slots.bytes + tasks.bytes +
            split.bytes + parts.bytes + Q.bytes + err.bytes + hot_cols.bytes + hot_slab.bytes +
-           err_partial.bytes;
+           err_partial.bytes + sl_cols.bytes + sl_rank.bytes + sl_train.bytes + sl_val.bytes + sl_z.bytes;
   }
 };
 

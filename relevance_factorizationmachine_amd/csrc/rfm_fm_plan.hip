@@ -581,6 +581,16 @@ int32_t rfm_fm_plan_info(const rfm_fm_plan* plan, int64_t* h_out8) {
   });
 }
 
+int32_t rfm_fm_plan_sliced(const rfm_fm_plan* plan, int32_t* h_out4) {
+  return guarded([&] {
+    RFM_REQUIRE(plan && h_out4, "null pointer");
+    h_out4[0] = plan->sl_ns;
+    h_out4[1] = plan->sl_ns > 0 ? plan->sl_sw : 0;
+    h_out4[2] = plan->sl_ns > 0 ? plan->sl_n_cached : 0;
+    h_out4[3] = plan->sl_ns > 0 ? 1 << plan->sl_ml_log2 : 0;
+  });
+}
+
 int32_t rfm_fm_plan_layout(const rfm_fm_plan* plan, int32_t* h_out4) {
   return guarded([&] {
     RFM_REQUIRE(plan && h_out4, "null pointer");

@@ -36,6 +36,7 @@ namespace rfm {
 constexpr int kSlBlock = 1024;
 constexpr int kSlWaves = kSlBlock / kWave;
 constexpr int kSlPairs = 2;    // pairs of factors per lane: a wavefront covers 256 factors of a row
+constexpr int kSlFill = 8;     // cached columns a wavefront requests together when it fills the LDS copy
 constexpr int kSlGlobals = 2;  // gathers of a row's uncached entries requested a row ahead
 #ifndef RFM_SL_BATCH
 #define RFM_SL_BATCH 4
@@ -124,14 +125,16 @@ __global__ __launch_bounds__(kSlBlock) void fm_logit_slices_kernel(SlicedArgs a)
   const int ZOFF = H * RS;  // the row of zeros: what an entry that is not cached reads
   const int f0 = slice * SW;
   const int width = SW < k - f0 ? SW : k - f0;
-  // lane l holds the factors 4 l .. 4 l + 3 of the slice as two pairs (16-byte loads); an idle
-  // pair re-reads the slice's first pair and is dropped from the sums
+  // lane l holds the pairs of factors l and 64 + l of the slice (16-byte loads: an instruction
+  // reads 1 KiB of consecutive bytes -- with the pairs 2 l and 2 l + 1 instead, the lanes of a
+  // ds_read_b128 sat 32 bytes apart and half of the LDS cycles were bank conflicts); an idle pair
+  // re-reads the slice's first pair and is dropped from the sums
   bool pair_ok[kSlPairs];
-  int loff[kSlPairs];
+  int loff[kSlPairs];  // the pair's first factor
 #pragma unroll
   for (int p = 0; p < kSlPairs; ++p) {
-    pair_ok[p] = 2 * (kSlPairs * lane + p) < width;
-    loff[p] = pair_ok[p] ? 2 * (kSlPairs * lane + p) : 0;
+    pair_ok[p] = 2 * (kWave * p + lane) < width;
+    loff[p] = pair_ok[p] ? 2 * (kWave * p + lane) : 0;
   }
   const double* Vs = a.V + f0;  // the slice of row 0
   const double w0 = slice == 0 ? a.w0[0] : 0.0;
@@ -142,25 +145,25 @@ __global__ __launch_bounds__(kSlBlock) void fm_logit_slices_kernel(SlicedArgs a)
 #endif
   RFM_STAMP(0);
 
-  // the cached columns' slices [H + 1][SW | norm | -]: a wavefront per column, four columns'
+  // the cached columns' slices [H + 1][SW | norm | -]: a wavefront per column, kSlFill columns'
   // loads in flight (no load under a branch, see `request` below: past the last column,
   // column 0 again, not stored); row H is zero
   for (int i = tid; i < RS / 8; i += kSlBlock) reinterpret_cast<double*>(sl_lds + ZOFF)[i] = 0.0;
-  for (int hb = 0; hb < H; hb += kSlWaves * 4) {
-    int col[4];
-    double2 v[4][kSlPairs];
+  for (int hb = 0; hb < H; hb += kSlWaves * kSlFill) {
+    int col[kSlFill];
+    double2 v[kSlFill][kSlPairs];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kSlFill; ++u) {
       const int h = hb + u * kSlWaves + wave;
       col[u] = a.cached_cols[h < H ? h : 0];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < kSlFill; ++u)
 #pragma unroll
       for (int p = 0; p < kSlPairs; ++p)
         v[u][p] = *reinterpret_cast<const double2*>(Vs + int64_t(col[u]) * k + loff[p]);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kSlFill; ++u) {
       const int h = hb + u * kSlWaves + wave;
       double n = 0.0;
 #pragma unroll
@@ -172,8 +175,8 @@ __global__ __launch_bounds__(kSlBlock) void fm_logit_slices_kernel(SlicedArgs a)
       if (h < H) {  // (uniform in the wavefront)
 #pragma unroll
         for (int p = 0; p < kSlPairs; ++p)
-          if (2 * (kSlPairs * lane + p) < SW)
-            *reinterpret_cast<double2*>(sl_lds + h * RS + (kSlPairs * lane + p) * 16) = v[u][p];
+          if (2 * (kWave * p + lane) < SW)
+            *reinterpret_cast<double2*>(sl_lds + h * RS + (kWave * p + lane) * 16) = v[u][p];
         if (lane == kWave - 1) *reinterpret_cast<double*>(sl_lds + h * RS + SW * 8) = n;
       }
     }
@@ -225,24 +228,29 @@ __global__ __launch_bounds__(kSlBlock) void fm_logit_slices_kernel(SlicedArgs a)
     }
   };
   const auto consume = [&](int off, int col, double x, const SlAhead& g) {
-    // cached entries: lanes 0 .. nh - 1; a batch's lanes past nh read the row of zeros
+    // cached entries: lanes 0 .. nh - 1, whole batches and then the last one to three
 #pragma unroll
     for (int b = 0; b < kWave; b += kSlBatch) {
       if (b < g.nh) {  // (uniform)
+        const int live = g.nh - b;  // entries of this batch
         double2 hv[kSlBatch][kSlPairs];
 #pragma unroll
         for (int u = 0; u < kSlBatch; ++u) {
-          const char* row = sl_lds + __builtin_amdgcn_readlane(off, b + u);
+          if (u == 0 || u < live) {
+            const char* row = sl_lds + __builtin_amdgcn_readlane(off, b + u);
 #pragma unroll
-          for (int p = 0; p < kSlPairs; ++p) hv[u][p] = *reinterpret_cast<const double2*>(row + loff[p] * 8);
+            for (int p = 0; p < kSlPairs; ++p) hv[u][p] = *reinterpret_cast<const double2*>(row + loff[p] * 8);
+          }
         }
 #pragma unroll
         for (int u = 0; u < kSlBatch; ++u) {
-          const double xj = readlane_f64(x, b + u);
+          if (u == 0 || u < live) {
+            const double xj = readlane_f64(x, b + u);
 #pragma unroll
-          for (int p = 0; p < kSlPairs; ++p) {
-            q[2 * p] = fma(hv[u][p].x, xj, q[2 * p]);
-            q[2 * p + 1] = fma(hv[u][p].y, xj, q[2 * p + 1]);
+            for (int p = 0; p < kSlPairs; ++p) {
+              q[2 * p] = fma(hv[u][p].x, xj, q[2 * p]);
+              q[2 * p + 1] = fma(hv[u][p].y, xj, q[2 * p + 1]);
+            }
           }
         }
       }

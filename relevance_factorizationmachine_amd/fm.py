@@ -106,6 +106,13 @@ class FmPlan:
         return dict(zip(("row_blocks", "row_block_bytes", "lanes_per_row", "longest_row"),
                         (int(v) for v in out)))
 
+    def sliced(self) -> dict:
+        """The sliced loss forwards of ``rfm_fm_train`` (even factor counts above 128)."""
+        out = np.zeros(4, dtype=np.int32)
+        _lib.check(self.rt.lib.rfm_fm_plan_sliced(self.handle, out.ctypes.data))
+        return dict(zip(("slices", "factors_per_slice", "cached_columns", "records_per_row"),
+                        (int(v) for v in out)))
+
     def hot_columns(self) -> np.ndarray:
         out = np.zeros(max(self.info()["hot_columns"], 1), dtype=np.int32)
         _lib.check(self.rt.lib.rfm_fm_plan_hot_columns(self.handle, out.ctypes.data, out.shape[0]))
@@ -206,7 +213,7 @@ class FactorizationMachines(PointwiseBaseRecommender):
         hot = -2 if self.deterministic else self.hot_min_count
         plan = (plan_cache(rt).take(rt, tr, y, p, self.n_factors, self.batch_size, hot) if keep
                 else FmPlan(rt, tr, y, p, self.n_factors, self.batch_size, hot))
-        self.plan_info = dict(plan.info(), **plan.layout())  # (what the last fit trained with)
+        self.plan_info = dict(plan.info(), **plan.layout(), **plan.sliced())  # (what the last fit trained with)
         tl = rt.empty((self.n_epochs,), y.dtype)
         vl = rt.empty((self.n_epochs,), y.dtype)
         # an empty validation set: the reference's mean over no rows is nan (src/base.py:61)

@@ -1131,6 +1131,9 @@ def test_sliced_loss_forward_gives_the_same_losses(rfm, monkeypatch, k, n_cols, 
     (a, tra, vaa), (b, trb, vab) = fits["plain"], fits["sliced"]
     np.testing.assert_array_equal(a.V(), b.V())
     assert rel_err(trb, tra) < 1e-12 and rel_err(vab, vaa) < 1e-12
+    info = b.plan_info
+    assert info["slices"] == (1 if k <= 256 else 2 if k <= 512 else 4) and info["cached_columns"] >= 4
+    assert info["slices"] * info["factors_per_slice"] >= k > (info["slices"] - 1) * info["factors_per_slice"]
     ref = cpu_ref.fm_fit(train, val, n_epochs=its, n_factors=k, lr=lr, batch_size=batch, seed=5)
     assert rel_err(trb, ref["train_loss"]) < TIGHT and rel_err(vab, ref["val_loss"]) < TIGHT
     assert_elementwise(trb, ref["train_loss"], what="train loss")

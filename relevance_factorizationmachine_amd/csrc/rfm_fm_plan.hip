@@ -455,7 +455,7 @@ rfm_fm_plan* build_plan(rfm_ctx* ctx, const int64_t* d_indptr, const int32_t* d_
         if (len(c) * 64 >= n_rows) sl_cols.push_back(int32_t(c));
       std::stable_sort(sl_cols.begin(), sl_cols.end(),
                        [&](int32_t x, int32_t y) { return len(size_t(x)) > len(size_t(y)); });
-      const size_t cap = size_t(kSlicedLds - 2048) / size_t(sliced_row_bytes(sw)) - 1;  // (+ the zero row)
+      const size_t cap = size_t(kSlicedLds - kSlicedLdsSlack - 1024) / size_t(sliced_row_bytes(sw)) - 1;  // (+ the zero row)
       if (sl_cols.size() > cap) sl_cols.resize(cap);
       sl_rank.assign(nf, -1);
       for (size_t h = 0; h < sl_cols.size(); ++h) sl_rank[size_t(sl_cols[h])] = int32_t(h);

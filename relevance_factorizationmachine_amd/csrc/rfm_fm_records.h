@@ -73,6 +73,7 @@ struct PrepRec {  // in slot order
 
 // Sliced loss forwards (rfm_fm_sliced.hpp): LDS of a workgroup (the cached columns' slices)
 constexpr int kSlicedLds = 160 << 10;
+constexpr int kSlicedLdsSlack = 2048;  // readable bytes after the last row (unclamped reads of idle lanes)
 struct SlEnt {   // one entry of a translated log, 16 B.  A row's records: the cached columns'
                  // entries first (in row order), then the others, then padding
   int32_t off;   // byte offset of the column's slice in the workgroup's LDS copy; the ZERO row's

@@ -73,7 +73,7 @@ struct SlicedArgs {
 };
 
 inline size_t sliced_lds_bytes(int n_cached, int sw) {
-  return size_t(n_cached + 1) * size_t(sliced_row_bytes(sw));
+  return size_t(n_cached + 1) * size_t(sliced_row_bytes(sw)) + kSlicedLdsSlack;
 }
 
 __device__ inline double readlane_f64(double v, int j) {
@@ -145,6 +145,41 @@ __global__ __launch_bounds__(kSlBlock) void fm_logit_slices_kernel(SlicedArgs a)
 #endif
   RFM_STAMP(0);
 
+  // the rows of this wavefront: row_begin + wave + 16 j
+  const int64_t rows_wg = row_end - row_begin;
+  const int my_rows = wave < rows_wg ? int((rows_wg - wave + kSlWaves - 1) / kSlWaves) : 0;
+
+  // A block of up to 64 of them: lane j holds the row of its log that the wavefront's j-th row of
+  // the block is.  The first block's ids and its first two rows' records are requested BEFORE the
+  // workgroup fills its LDS copy (they do not depend on it).
+  int jb = 0, nj = 0, idv = 0;
+  const auto block = [&]() {
+    nj = my_rows - jb < kWave ? my_rows - jb : kWave;
+    const int64_t tl = row_begin + wave + int64_t(kSlWaves) * (jb + lane);
+    idv = 0;
+    if (lane < nj) idv = tl < a.n_a ? (a.row_ids ? a.row_ids[tl] : int(tl)) : int(tl - a.n_a);
+  };
+  // (lanes past the row's records, and rows past the block, read ONE padding record instead: a
+  // select of the ADDRESS -- a select of the loaded value would let the compiler put the load
+  // under a branch, and a load under a branch ends the pipeline)
+  const auto records = [&](int j, int& off, int& col, double& x) {
+    const int jj = j < nj ? j : nj - 1;
+    const int64_t t = row_begin + wave + int64_t(kSlWaves) * (jb + jj);
+    const int r = __builtin_amdgcn_readlane(idv, jj);
+    const SlEnt* row = (t < a.n_a ? a.tr_a : a.tr_b) + (int64_t(r) << a.ml_log2);
+    const SlEnt e = *(j < nj && lane < ML ? row + lane : a.pad);
+    off = e.off;
+    col = e.col;
+    x = e.x;
+  };
+  int o0 = 0, k0 = kSlPad, o1 = 0, k1 = kSlPad;
+  double x0 = 0.0, x1 = 0.0;
+  if (my_rows > 0) {
+    block();
+    records(0, o0, k0, x0);
+    records(1, o1, k1, x1);
+  }
+
   // the cached columns' slices [H + 1][SW | norm | -]: a wavefront per column, kSlFill columns'
   // loads in flight (no load under a branch, see `request` below: past the last column,
   // column 0 again, not stored); row H is zero
@@ -185,10 +220,6 @@ __global__ __launch_bounds__(kSlBlock) void fm_logit_slices_kernel(SlicedArgs a)
   __syncthreads();
   RFM_STAMP(2);
 
-  // the rows of this wavefront: row_begin + wave + 16 j
-  const int64_t rows_wg = row_end - row_begin;
-  const int my_rows = wave < rows_wg ? int((rows_wg - wave + kSlWaves - 1) / kSlWaves) : 0;
-
   double q[2 * kSlPairs], s2[kSlPairs];  // (s2 per pair: an idle pair's sums are dropped whole)
   // Every load of the pipeline is UNCONDITIONAL and its value is always used: with a load under
   // a branch the compiler cannot count how many newer requests may be outstanding when an older
@@ -228,7 +259,10 @@ __global__ __launch_bounds__(kSlBlock) void fm_logit_slices_kernel(SlicedArgs a)
     }
   };
   const auto consume = [&](int off, int col, double x, const SlAhead& g) {
-    // cached entries: lanes 0 .. nh - 1, whole batches and then the last one to three
+    // cached entries: lanes 0 .. nh - 1, whole batches and then the last one to three.  (The LDS
+    // reads are NOT clamped for idle pairs -- pair p sits 1 KiB after pair 0, one address register
+    // and an immediate offset; what an idle pair reads is dropped by pair_ok, and the LDS
+    // allocation ends 2 KiB after the row of zeros)
 #pragma unroll
     for (int b = 0; b < kWave; b += kSlBatch) {
       if (b < g.nh) {  // (uniform)
@@ -239,7 +273,7 @@ __global__ __launch_bounds__(kSlBlock) void fm_logit_slices_kernel(SlicedArgs a)
           if (u == 0 || u < live) {
             const char* row = sl_lds + __builtin_amdgcn_readlane(off, b + u);
 #pragma unroll
-            for (int p = 0; p < kSlPairs; ++p) hv[u][p] = *reinterpret_cast<const double2*>(row + loff[p] * 8);
+            for (int p = 0; p < kSlPairs; ++p) hv[u][p] = *reinterpret_cast<const double2*>(row + lane * 16 + p * (kWave * 16));
           }
         }
 #pragma unroll
@@ -275,30 +309,10 @@ __global__ __launch_bounds__(kSlBlock) void fm_logit_slices_kernel(SlicedArgs a)
     return pl;
   };
 
-  for (int jb = 0; jb < my_rows; jb += kWave) {
-    const int nj = my_rows - jb < kWave ? my_rows - jb : kWave;
-    // lane j: the row of its log that this wavefront's j-th row of the block is
-    const int64_t tl = row_begin + wave + int64_t(kSlWaves) * (jb + lane);
-    int idv = 0;
-    if (lane < nj) idv = tl < a.n_a ? (a.row_ids ? a.row_ids[tl] : int(tl)) : int(tl - a.n_a);
-    // (lanes past the row's records, and rows past the block, read ONE padding record instead:
-    // a select of the ADDRESS -- a select of the loaded value would let the compiler put the load
-    // under a branch, and a load under a branch ends the pipeline)
-    const auto records = [&](int j, int& off, int& col, double& x) {
-      const int jj = j < nj ? j : nj - 1;
-      const int64_t t = row_begin + wave + int64_t(kSlWaves) * (jb + jj);
-      const int r = __builtin_amdgcn_readlane(idv, jj);
-      const SlEnt* row = (t < a.n_a ? a.tr_a : a.tr_b) + (int64_t(r) << a.ml_log2);
-      const SlEnt e = *(j < nj && lane < ML ? row + lane : a.pad);
-      off = e.off;
-      col = e.col;
-      x = e.x;
-    };
-    int o0, k0, o1, k1, o2, k2;
-    double x0, x1, x2;
+  while (jb < my_rows) {
+    int o2, k2;
+    double x2;
     SlAhead g0, g1;
-    records(0, o0, k0, x0);
-    records(1, o1, k1, x1);
     request(o0, k0, x0, g0);
     RFM_STAMP(3);
     for (int j = 0; j < nj; ++j) {
@@ -363,6 +377,12 @@ __global__ __launch_bounds__(kSlBlock) void fm_logit_slices_kernel(SlicedArgs a)
       g0 = g1;
     }
     RFM_STAMP(6);
+    jb += kWave;
+    if (jb < my_rows) {
+      block();
+      records(0, o0, k0, x0);
+      records(1, o1, k1, x1);
+    }
   }
 }
 

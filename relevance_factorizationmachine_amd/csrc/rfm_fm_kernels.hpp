@@ -1030,8 +1030,14 @@ __device__ inline int group_scan(int v, int l) {
 // ahead of the loop from the row ids, see PrepRec) instead of being discovered from the bitmap:
 // first load = the records, second level = residuals + Q / V rows, third = the stores.  Sums
 // and their order are those of the bitmap form, bit for bit.
+// (waves per SIMD the chunk-per-workgroup form is compiled for: its grid is task workgroups x
+// chunks -- 1 400 workgroups at the published point -- and how many of them are resident sets
+// the launch's length; RFM_CONS_CH_WAVES=0: no cap)
+#ifndef RFM_CONS_CH_WAVES
+#define RFM_CONS_CH_WAVES 0
+#endif
 template <int LPR, int VEC, int NC, bool CH = false, bool PREP = false>
-__global__ __launch_bounds__(kBlock) void fm_consume_kernel(ConsArgs a) {
+__global__ __launch_bounds__(kBlock, (CH && RFM_CONS_CH_WAVES > 0 ? RFM_CONS_CH_WAVES : 1)) void fm_consume_kernel(ConsArgs a) {
   static_assert(!CH || NC == 1, "the chunked form holds one chunk per lane group");
   constexpr int GPB = kBlock / LPR;  // tasks of a workgroup
   constexpr int PLANES = WinShape<LPR>::PLANES;

@@ -901,14 +901,36 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
     // iterations are then computed together (rfm_fm_sliced.hpp)
     const int64_t sl_a = d_out_train_loss ? batch : 0, sl_b = d_out_val_loss ? n_val : 0;
     const SlicedGeom sliced = sliced_geom(ctx, plan, sl_a + sl_b);
+    // RFM_TRAIN_GRAPH=1 (timing experiment): the run's launches captured into one hipGraph
+    // and replayed once (GraphCapture restores the context's stream on every way out)
+    static const bool as_graph = env_int("RFM_TRAIN_GRAPH", 0) != 0;
+    // (prepared steps wait for an event on the host at every chunk: not inside a capture)
+    PrepRun prepared(ctx, plan, d_ids, batch, n_iters, !as_graph);
+    // one decision for the whole call (the partials of a run are finished together).  Only for
+    // factor counts of several chunks per lane: there it saves a launch (k = 400, B = 2 000:
+    // 0.098 -> 0.090 ms per iteration of fit()); at one chunk per lane the batch's rows are
+    // faster through the plan's padded row blocks than through the CSR arrays (config 3:
+    // 104.7 vs 111.6 us per iteration at B = 65 536).  RFM_MERGE_LOSS=0 / 2: never / always.
+    const int merge_mode = env_int("RFM_MERGE_LOSS", 1);
+    const bool merge_call = !sliced.ok && merge_mode != 0 && (merge_mode == 2 || shape_for(plan->k).nc > 1) &&
+                            d_out_train_loss && d_out_val_loss && (!prepared.on || prepared.records_only) &&
+                            forward_geom(ctx, batch + n_val, shape_for(plan->k), false).block == kBigBlock;
+    // The plain loss forwards (neither sliced nor merged) leave their rows' SCORES and take no
+    // logarithms: the two logs of a row's term are ~200 dependent f64 instructions, and a whole
+    // run of iterations' terms are computed by one launch instead (RFM_DEFER_LOSS=0: in the
+    // forward, staged through LDS).
+    const bool scores_only = !sliced.ok && !merge_call && sl_a + sl_b > 0 && env_int("RFM_DEFER_LOSS", 1) != 0;
+    const bool deferred = sliced.ok || scores_only;
+    const int zns = sliced.ok ? plan->sl_ns : 0;  // (0: the buffer holds scores)
     int64_t run_len = kRun;
-    const int64_t z_per_iter = int64_t(plan->sl_ns) * (sl_a + sl_b);
-    if (sliced.ok) {
+    const int64_t z_per_iter = int64_t(std::max(zns, 1)) * (sl_a + sl_b);
+    if (deferred) {
       run_len = std::max<int64_t>(1, std::min<int64_t>(kRun, (int64_t(256) << 20) / (z_per_iter * 8)));
       run_len = std::min(run_len, n_iters);
       plan->sl_z.ensure(size_t(run_len) * size_t(z_per_iter) * 8);
       // (the validation log is only known here: translated once per call)
-      if (sl_b > 0) sliced_translate(ctx, plan, d_val_indptr, d_val_indices, d_val_values, sl_b, plan->sl_val);
+      if (sliced.ok && sl_b > 0)
+        sliced_translate(ctx, plan, d_val_indptr, d_val_indices, d_val_values, sl_b, plan->sl_val);
     }
 #ifdef RFM_SLICED_STAMPS
     DevBuf stamps;
@@ -919,19 +941,19 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
 #endif
     const auto finish = [&](int64_t first, int64_t count) {
       if (count <= 0) return;
-      if (sliced.ok) {
+      if (deferred) {
         const auto shares = [&](int64_t rows) { return int(std::min<int64_t>(64, (rows + kBlock - 1) / kBlock)); };
         if (sl_a > 0) {
           train_parts = shares(sl_a);
           hipLaunchKernelGGL(loss_from_slices_kernel, dim3(train_parts, int(count)), dim3(kBlock), 0,
-                             ctx->stream, plan->sl_z.as<double>(), z_per_iter, plan->sl_ns,
+                             ctx->stream, plan->sl_z.as<double>(), z_per_iter, zns,
                              sl_a + sl_b, int64_t(0), sl_a, d_ids + first * batch, batch, d_y,
                              d_pscore, eps, train_rows, int64_t(kMaxFwdGrid));
         }
         if (sl_b > 0) {
           val_parts = shares(sl_b);
           hipLaunchKernelGGL(loss_from_slices_kernel, dim3(val_parts, int(count)), dim3(kBlock), 0,
-                             ctx->stream, plan->sl_z.as<double>(), z_per_iter, plan->sl_ns,
+                             ctx->stream, plan->sl_z.as<double>(), z_per_iter, zns,
                              sl_a + sl_b, sl_a, sl_b, static_cast<const int32_t*>(nullptr),
                              int64_t(0), d_val_y, d_val_pscore, eps, val_rows, int64_t(kMaxFwdGrid));
         }
@@ -945,21 +967,7 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
                            val_rows, int64_t(kMaxFwdGrid), val_parts, n_val, d_out_val_loss + first);
       RFM_HIP_CHECK(hipGetLastError());
     };
-    // RFM_TRAIN_GRAPH=1 (timing experiment): the run's launches captured into one hipGraph
-    // and replayed once (GraphCapture restores the context's stream on every way out)
-    static const bool as_graph = env_int("RFM_TRAIN_GRAPH", 0) != 0;
-    // (prepared steps wait for an event on the host at every chunk: not inside a capture)
-    PrepRun prepared(ctx, plan, d_ids, batch, n_iters, !as_graph);
     GraphCapture capture(ctx, as_graph && !ctx->profiling);
-    // one decision for the whole call (the partials of a run are finished together).  Only for
-    // factor counts of several chunks per lane: there it saves a launch (k = 400, B = 2 000:
-    // 0.098 -> 0.090 ms per iteration of fit()); at one chunk per lane the batch's rows are
-    // faster through the plan's padded row blocks than through the CSR arrays (config 3:
-    // 104.7 vs 111.6 us per iteration at B = 65 536).  RFM_MERGE_LOSS=0 / 2: never / always.
-    const int merge_mode = env_int("RFM_MERGE_LOSS", 1);
-    const bool merge_call = merge_mode != 0 && (merge_mode == 2 || shape_for(plan->k).nc > 1) &&
-                            d_out_train_loss && d_out_val_loss && (!prepared.on || prepared.records_only) &&
-                            forward_geom(ctx, batch + n_val, shape_for(plan->k), false).block == kBigBlock;
     int64_t run_first = 0;
     for (int64_t it = 0; it < n_iters; ++it) {
       const int32_t* ids = d_ids + it * batch;
@@ -1027,15 +1035,25 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
         f.V = d_V;
         f.k = plan->k;
         f.eps = eps;
-        train_parts = forward_loss_deferred(ctx, f, train_rows + slot * kMaxFwdGrid);
+        if (scores_only) {
+          f.out_pred = plan->sl_z.as<double>() + slot * z_per_iter;
+          launch_forward(ctx, f);
+        } else {
+          train_parts = forward_loss_deferred(ctx, f, train_rows + slot * kMaxFwdGrid);
+        }
       }
       if (d_out_val_loss && !merged) {
         FwdArgs f = forward_args(d_val_indptr, d_val_indices, d_val_values, nullptr, n_val,
                                  d_w0, d_w, d_V, plan->k);
-        f.y = d_val_y;
-        f.pscore = d_val_pscore;
         f.eps = eps;
-        val_parts = forward_loss_deferred(ctx, f, val_rows + slot * kMaxFwdGrid);
+        if (scores_only) {
+          f.out_pred = plan->sl_z.as<double>() + slot * z_per_iter + sl_a;
+          launch_forward(ctx, f);
+        } else {
+          f.y = d_val_y;
+          f.pscore = d_val_pscore;
+          val_parts = forward_loss_deferred(ctx, f, val_rows + slot * kMaxFwdGrid);
+        }
       }
       if (slot + 1 == run_len) {
         finish(run_first, run_len);

@@ -386,7 +386,8 @@ __global__ __launch_bounds__(kSlBlock) void fm_logit_slices_kernel(SlicedArgs a)
   }
 }
 
-// The loss terms of a RUN of iterations from their partial logits: block (x, y) sums a share
+// The loss terms of a RUN of iterations from their partial logits (ns >= 1 slices) or from their
+// scores (ns = 0: the plain forwards' out_pred): block (x, y) sums a share
 // of the rows [seg_first, seg_first + seg_rows) of iteration y in a fixed order;
 // loss_finish_many_kernel adds the shares.  ids (per iteration, ids_stride apart): the rows'
 // positions in y / p, or null for row t.
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void loss_from_slices_kernel(
     double zz = z[t];
     for (int s = 1; s < ns; ++s) zz += z[int64_t(s) * nr + t];
     const int64_t r = id ? int64_t(id[t]) : t;
-    acc += logloss_term(y[r], p[r], sigmoid_clipped(zz), eps);
+    acc += logloss_term(y[r], p[r], ns > 0 ? sigmoid_clipped(zz) : zz, eps);  // (ns = 0: z holds scores)
   }
   const double s = block_sum<kBlock>(acc, lds);
   if (threadIdx.x == 0) partial[int64_t(blockIdx.y) * partial_stride + blockIdx.x] = s;

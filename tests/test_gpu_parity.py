@@ -1185,3 +1185,32 @@ def test_sliced_loss_forward_keeps_a_non_finite_row_to_itself(rfm, monkeypatch, 
             assert np.isfinite(va1).all() and rel_err(va1, va0) < 1e-12
         else:
             assert np.isnan(va0).all() and np.isnan(va1).all()
+
+
+@pytest.mark.parametrize("shape,k,batch", [("kuairec_small", 16, 2000), ("coat", 300, 500), ("kuairec_small", 64, 20000)])
+def test_deferred_loss_logarithms_give_the_same_losses(rfm, monkeypatch, shape, k, batch):
+    """The plain loss forwards of rfm_fm_train leave their rows' scores and one launch per run of
+    iterations takes the logarithms (default; RFM_DEFER_LOSS=0: inside the forward, staged through LDS
+    in the many-rows shape): same parameters bit for bit, same loss curves up to the order of the sums,
+    both against the oracle.  150 iterations: more than one run of 128."""
+    pkg = rfm[0]
+    sh = synth.SHAPES[shape]
+    train, val = synth.make_log(sh, "FM", "IPS", seed=0)
+    its = 150 if batch <= 2000 else 5
+    fits = {}
+    monkeypatch.setenv("RFM_SLICED_LOSS", "0")
+    monkeypatch.setenv("RFM_MERGE_LOSS", "0")
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RFM_DEFER_LOSS", mode)
+        m = pkg.FactorizationMachines(estimator="IPS", n_epochs=its, n_factors=k, lr=9e-6, batch_size=batch,
+                                      seed=12345, n_features=train["features"].shape[1])
+        m.deterministic = True
+        fits[mode] = (m, *m.fit(train, val))
+    for name in ("RFM_DEFER_LOSS", "RFM_SLICED_LOSS", "RFM_MERGE_LOSS"):
+        monkeypatch.delenv(name)
+    (a, tra, vaa), (b, trb, vab) = fits["0"], fits["1"]
+    np.testing.assert_array_equal(a.V(), b.V())
+    assert len(trb) == its and rel_err(trb, tra) < 1e-13 and rel_err(vab, vaa) < 1e-13
+    n_ref = min(its, 8)
+    ref = cpu_ref.fm_fit(train, val, n_epochs=n_ref, n_factors=k, lr=9e-6, batch_size=batch, seed=12345)
+    assert rel_err(trb[:n_ref], ref["train_loss"]) < TIGHT and rel_err(vab[:n_ref], ref["val_loss"]) < TIGHT

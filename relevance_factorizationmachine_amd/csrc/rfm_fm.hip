@@ -83,9 +83,9 @@ bool forward_many_rows(const rfm_ctx* ctx, int64_t rows, int n_factors) {
 }
 
 // one instantiation: raises its dynamic-LDS limit when a launch needs more than the default
-template <int L, int Vv, int N, int BLOCK, int R, bool REC, bool ELL, bool DET, bool SEG = false>
+template <int L, int Vv, int N, int BLOCK, int R, bool REC, bool ELL, bool DET, bool SEG = false, bool XTRA = false>
 void launch_forward_as(rfm_ctx* ctx, const FwdArgs& a, const FwdGeom& geom, size_t lds) {
-  const auto kern = &fm_forward_kernel<L, Vv, N, BLOCK, R, REC, ELL, DET, SEG>;
+  const auto kern = &fm_forward_kernel<L, Vv, N, BLOCK, R, REC, ELL, DET, SEG, XTRA>;
   // (the attribute belongs to the function ON a device: kept per device; atomics because
   // contexts of different host threads share the instantiation)
   static std::atomic<size_t> lds_allowed[kMaxDevices];
@@ -127,6 +127,11 @@ void launch_forward_shape(rfm_ctx* ctx, const FwdArgs& a, const FwdGeom& geom, s
     }
   }
   RFM_REQUIRE(!fixed, "fixed-order hot sums are not built for this factor count");
+  if (a.n_rows_x > 0) {  // (XTRA form: the last workgroups only score another batch's rows)
+    if (a.ell) return launch_forward_as<L, Vv, N, kSmallBlock, 1, true, true, false, false, true>(ctx, a, geom, lds);
+    RFM_REQUIRE(a.ent && a.rows, "the plan holds no row records");
+    return launch_forward_as<L, Vv, N, kSmallBlock, 1, true, false, false, false, true>(ctx, a, geom, lds);
+  }
   if (a.ell) return launch_forward_as<L, Vv, N, kSmallBlock, 1, true, true, false>(ctx, a, geom, lds);
   RFM_REQUIRE(a.ent && a.rows, "the plan holds no row records");
   return launch_forward_as<L, Vv, N, kSmallBlock, 1, true, false, false>(ctx, a, geom, lds);
@@ -302,11 +307,24 @@ struct PrepView {
 };
 
 // the three launches of one step; grad == nullptr -> update in place
+// rows of the plan's log that a step's forward launch scores on the side (fm_forward_kernel, XTRA)
+struct XtraRows {
+  const int32_t* ids;
+  int64_t n;
+  double* out_pred;
+};
+// whether a step of `batch` rows can take them along: the one-row forward shape, arrival-order hot
+// sums, rows through the plan's records
+bool step_takes_extra_rows(const rfm_ctx* ctx, const rfm_fm_plan* plan, int64_t batch) {
+  return forward_geom(ctx, batch, shape_for(plan->k), true).block == kSmallBlock &&
+         !(plan->hot_fixed && plan->n_hot > 0);
+}
+
 void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
                   const int32_t* d_indices, const double* d_values, const double* d_y,
                   const double* d_pscore, const int32_t* d_row_ids, int64_t batch, double* d_w0,
                   double* d_w, double* d_V, double lr, double* d_grad, int32_t* d_touch = nullptr,
-                  int32_t touch_id = 0, const PrepView* prep = nullptr) {
+                  int32_t touch_id = 0, const PrepView* prep = nullptr, const XtraRows* xtra = nullptr) {
   const int k = plan->k;
   const Shape s = shape_for(k);
   (void)d_indptr;
@@ -356,12 +374,24 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
 #ifdef RFM_ABLATE
   f.ablate = env_int("RFM_ABLATE_MASK", 0);
 #endif
-  const FwdGeom geom = forward_geom(ctx, batch, s, true);
+  const FwdGeom geom = forward_geom(ctx, batch, s, true);  // (the step's own workgroups: geom.grid slabs)
+  FwdGeom launch = geom;
+  if (xtra && xtra->n > 0) {
+    RFM_REQUIRE(geom.block == kSmallBlock && !(f.hot_fixed && f.n_hot > 0) && !(prep && prep->E),
+                "this step cannot score extra rows");
+    const FwdGeom gx = forward_geom(ctx, xtra->n, s, true);
+    RFM_REQUIRE(gx.block == kSmallBlock, "extra rows: unexpected geometry");
+    f.grid_main = geom.grid;
+    f.row_ids_x = xtra->ids;
+    f.n_rows_x = xtra->n;
+    f.out_pred_x = xtra->out_pred;
+    launch.grid = geom.grid + gx.grid;
+  }
   ctx->prof_mark();
 #ifdef RFM_ABLATE
   if (!(f.ablate & 64))
 #endif
-    launch_forward(ctx, f, geom);
+    launch_forward(ctx, f, launch);
   ctx->prof_mark();
 
   if (d_grad && !d_touch) {  // dense gradient: every element is written
@@ -968,14 +998,30 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
       RFM_HIP_CHECK(hipGetLastError());
     };
     GraphCapture capture(ctx, as_graph && !ctx->profiling);
-    int64_t run_first = 0;
+    // Small batches: the train-loss forward of iteration it - 1 reads the parameters that step
+    // it's forward reads -- it RIDES in that launch (extra workgroups that only score the previous
+    // batch's rows; fm_forward_kernel's XTRA form), and only the last iteration's is a launch of
+    // its own.  A run's logarithms then wait for the next step's launch.  (RFM_RIDE_LOSS=0: never.)
+    const bool ride = scores_only && d_out_train_loss && step_takes_extra_rows(ctx, plan, batch) &&
+                      !(prepared.on && !prepared.records_only) && env_int("RFM_RIDE_LOSS", 1) != 0;
+    int64_t run_first = 0, pending_first = -1, pending_count = 0;
     for (int64_t it = 0; it < n_iters; ++it) {
       const int32_t* ids = d_ids + it * batch;
       const int64_t slot = it - run_first;
       PrepView pv{};
       const bool is_prepared = prepared.view(it, pv);
+      XtraRows prev{};
+      if (ride && it > 0) {
+        const int64_t prev_slot = pending_count > 0 ? pending_count - 1 : slot - 1;
+        prev = XtraRows{ids - batch, batch, plan->sl_z.as<double>() + prev_slot * z_per_iter};
+      }
       enqueue_step(ctx, plan, d_indptr, d_indices, d_values, d_y, d_pscore, ids, batch, d_w0,
-                   d_w, d_V, lr, nullptr, nullptr, 0, is_prepared ? &pv : nullptr);
+                   d_w, d_V, lr, nullptr, nullptr, 0, is_prepared ? &pv : nullptr,
+                   prev.n > 0 ? &prev : nullptr);
+      if (pending_count > 0) {  // (before this iteration's forwards reuse the run's first slots)
+        finish(pending_first, pending_count);
+        pending_count = 0;
+      }
       // both losses asked for: ONE launch over the batch's rows of the training log and the
       // validation log (RFM_MERGE_LOSS=0: two launches)
       bool merged = false;
@@ -1019,7 +1065,7 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
         train_parts = val_parts = parts;
         merged = true;
       }
-      if (d_out_train_loss && !merged) {
+      if (d_out_train_loss && !merged && !(ride && it + 1 < n_iters)) {
         // same batch, new parameters (src/fm.py:90-96), through the plan's records
         FwdArgs f{};
         f.ent = plan->ent.as<Entry>();
@@ -1056,7 +1102,12 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
         }
       }
       if (slot + 1 == run_len) {
-        finish(run_first, run_len);
+        if (ride && it + 1 < n_iters) {  // (its last train scores arrive with the next step)
+          pending_first = run_first;
+          pending_count = run_len;
+        } else {
+          finish(run_first, run_len);
+        }
         run_first = it + 1;
       }
       prepared.done(it);

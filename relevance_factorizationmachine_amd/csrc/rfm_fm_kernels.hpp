@@ -150,6 +150,14 @@ struct FwdArgs {
   double* loss_partial;  // nullable: [gridDim.x]
   double eps;
   int32_t ablate;  // -DRFM_ABLATE builds only: bit mask of parts to skip (timing experiments)
+  // XTRA form (with REC, one-row shape): workgroups grid_main .. gridDim.x - 1 only SCORE the rows
+  // row_ids_x[0 .. n_rows_x) of the same plan (-> out_pred_x) -- no Q rows, marks, hot sums or
+  // residuals: the train-loss forward of the previous batch, which reads the same parameters as
+  // this step's forward, rides in its launch (rfm_fm_train)
+  int32_t grid_main;
+  const int32_t* row_ids_x;
+  int64_t n_rows_x;
+  double* out_pred_x;
 };
 
 #ifdef RFM_ABLATE
@@ -180,10 +188,31 @@ struct FwdArgs {
 // DET (with REC): the hot-class sums in a fixed order (hot_fixed_order) instead of LDS atomics.
 // SEG (without REC, many-rows shape): two logs in one launch, see FwdArgs.
 template <int LPR, int VEC, int NC, int BLOCK, int R, bool REC, bool ELL = false, bool DET = false,
-          bool SEG = false>
+          bool SEG = false, bool XTRA = false>
 __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)) void fm_forward_kernel(
     FwdArgs a) {
   constexpr int GPB = BLOCK / LPR;  // lane groups per block
+  // workgroup index and count among the workgroups of its kind (XTRA: the step's, or the ones
+  // that only score the extra rows -- a workgroup-uniform switch of what the arguments mean)
+  unsigned bx = blockIdx.x, gx = gridDim.x;
+  if constexpr (XTRA && REC) {
+    if (int(blockIdx.x) >= a.grid_main) {
+      bx = blockIdx.x - a.grid_main;
+      gx = gridDim.x - a.grid_main;
+      a.row_ids = a.row_ids_x;
+      a.n_rows = a.n_rows_x;
+      a.n_hot = 0;
+      a.slot_mark = nullptr;
+      a.slot_bits = nullptr;
+      a.out_Q = nullptr;
+      a.out_err = nullptr;
+      a.err_partial = nullptr;
+      a.loss_partial = nullptr;
+      a.out_pred = a.out_pred_x;
+    } else {
+      gx = a.grid_main;
+    }
+  }
   constexpr bool seg = SEG && !REC;
   extern __shared__ double dyn_lds[];
   const int tid = threadIdx.x;
@@ -233,8 +262,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
     __syncthreads();
   }
 
-  for (int64_t base = int64_t(blockIdx.x) * (GPB * R); base < a.n_rows;
-       base += int64_t(gridDim.x) * (GPB * R)) {
+  for (int64_t base = int64_t(bx) * (GPB * R); base < a.n_rows;
+       base += int64_t(gx) * (GPB * R)) {
     int64_t t[R];
     int32_t r[R];  // rows of a log (or of a batch) fit 31 bits
     // entry offsets: the plan checks that they fit 31 bits; the caller's CSR is taken as it is
@@ -265,7 +294,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
     // its row blocks, so that the next trip's first two dependent loads find their lines
     // on chip instead of waiting for memory
     int32_t nxt[R];
-    const int64_t nbase = base + int64_t(gridDim.x) * (GPB * R);
+    const int64_t nbase = base + int64_t(gx) * (GPB * R);
     constexpr bool ell = REC && ELL;
     const bool warm = ell && BLOCK == kBigBlock && a.row_ids && nbase < a.n_rows;
     int32_t* parked = reinterpret_cast<int32_t*>(red);  // (red is only used after the trips)
@@ -681,7 +710,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
             // bit 512: what carrying the five most frequent columns (present in every row of the
             // KuaiRec-shaped log) in registers across a workgroup's trips would save at best --
             // their adds vanish on every trip after a workgroup's first
-            if ((a.ablate & 512) && -1 - eh[i].slot < 5 && base >= int64_t(gridDim.x) * (GPB * R)) continue;
+            if ((a.ablate & 512) && -1 - eh[i].slot < 5 && base >= int64_t(gx) * (GPB * R)) continue;
 #endif
             if (RFM_KEEP(a, 8)) {
 #pragma unroll
@@ -712,20 +741,20 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
     // slab layout [H][gridDim.x][k+2]: the slabs of one column are contiguous
     for (int i = tid; i < H * hot_w; i += BLOCK) {
       const int h = i / hot_w, f = i % hot_w;
-      a.hot_slab[(int64_t(h) * gridDim.x + blockIdx.x) * hot_w + f] = hot[i];
+      a.hot_slab[(int64_t(h) * gx + bx) * hot_w + f] = hot[i];
     }
   }
   if (a.err_partial) {
     const double s = block_sum<BLOCK>(err_acc, red);
-    if (tid == 0) a.err_partial[blockIdx.x] = s;
+    if (tid == 0) a.err_partial[bx] = s;
   }
   if (a.loss_partial) {
     const double s = block_sum<BLOCK>(loss_acc, red);
-    if (tid == 0) a.loss_partial[blockIdx.x] = s;
+    if (tid == 0) a.loss_partial[bx] = s;
   }
   if (seg && a.loss_partial2) {
     const double s = block_sum<BLOCK>(loss_acc2, red);
-    if (tid == 0) a.loss_partial2[blockIdx.x] = s;
+    if (tid == 0) a.loss_partial2[bx] = s;
   }
 }
 

@@ -1192,7 +1192,8 @@ def test_deferred_loss_logarithms_give_the_same_losses(rfm, monkeypatch, shape, 
     """The plain loss forwards of rfm_fm_train leave their rows' scores and one launch per run of
     iterations takes the logarithms (default; RFM_DEFER_LOSS=0: inside the forward, staged through LDS
     in the many-rows shape): same parameters bit for bit, same loss curves up to the order of the sums,
-    both against the oracle.  150 iterations: more than one run of 128."""
+    both against the oracle.  150 iterations: more than one run of 128 (a run's last train-loss rows are
+    scored in the NEXT run's first step when they ride in the forward launch, RFM_RIDE_LOSS)."""
     pkg = rfm[0]
     sh = synth.SHAPES[shape]
     train, val = synth.make_log(sh, "FM", "IPS", seed=0)
@@ -1200,16 +1201,22 @@ def test_deferred_loss_logarithms_give_the_same_losses(rfm, monkeypatch, shape, 
     fits = {}
     monkeypatch.setenv("RFM_SLICED_LOSS", "0")
     monkeypatch.setenv("RFM_MERGE_LOSS", "0")
-    for mode in ("0", "1"):
-        monkeypatch.setenv("RFM_DEFER_LOSS", mode)
+    for mode, defer, ride in (("0", "0", "1"), ("1", "1", "1"), ("apart", "1", "0")):
+        monkeypatch.setenv("RFM_DEFER_LOSS", defer)
+        monkeypatch.setenv("RFM_RIDE_LOSS", ride)
         m = pkg.FactorizationMachines(estimator="IPS", n_epochs=its, n_factors=k, lr=9e-6, batch_size=batch,
                                       seed=12345, n_features=train["features"].shape[1])
-        m.deterministic = True
+        m.hot_min_count = -1  # (no on-chip class: every sum in a fixed order, and the rows may ride)
         fits[mode] = (m, *m.fit(train, val))
-    for name in ("RFM_DEFER_LOSS", "RFM_SLICED_LOSS", "RFM_MERGE_LOSS"):
+    for name in ("RFM_DEFER_LOSS", "RFM_RIDE_LOSS", "RFM_SLICED_LOSS", "RFM_MERGE_LOSS"):
         monkeypatch.delenv(name)
-    (a, tra, vaa), (b, trb, vab) = fits["0"], fits["1"]
+    (a, tra, vaa), (b, trb, vab), (c, trc, vac) = fits["0"], fits["1"], fits["apart"]
+    # (the train-loss rows riding in the next step's forward launch -- small batches -- or scored by a
+    # launch of their own: the same scores, bit for bit)
+    np.testing.assert_array_equal(np.asarray(trb), np.asarray(trc))
+    np.testing.assert_array_equal(np.asarray(vab), np.asarray(vac))
     np.testing.assert_array_equal(a.V(), b.V())
+    np.testing.assert_array_equal(c.V(), b.V())
     assert len(trb) == its and rel_err(trb, tra) < 1e-13 and rel_err(vab, vaa) < 1e-13
     n_ref = min(its, 8)
     ref = cpu_ref.fm_fit(train, val, n_epochs=n_ref, n_factors=k, lr=9e-6, batch_size=batch, seed=12345)

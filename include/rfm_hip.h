@@ -173,6 +173,14 @@ int32_t rfm_fm_plan_layout(const rfm_fm_plan* plan, int32_t* h_out4);
  * the factors (0: this plan has none), [1]=factors per slice, [2]=columns whose slice a workgroup
  * keeps in LDS, [3]=records per row of the translated logs */
 int32_t rfm_fm_plan_sliced(const rfm_fm_plan* plan, int32_t* h_out4);
+/* Optional: the validation log that coming rfm_fm_train calls on this plan will name (device CSR
+ * arrays).  A plan with sliced loss forwards keeps its translated form, and calls that pass the SAME
+ * three pointers and row count skip the per-call translation (a fit() that trains one iteration per
+ * call).  The caller promises that the arrays do not change until it registers again; any other
+ * arrays are translated per call as before. */
+int32_t rfm_fm_plan_register_validation(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
+                                        const int32_t* d_indices, const double* d_values,
+                                        int64_t n_rows);
 /* the hot columns (ascending), h_out[0 .. info[2]); capacity = room in h_out */
 int32_t rfm_fm_plan_hot_columns(const rfm_fm_plan* plan, int32_t* h_out, int32_t capacity);
 

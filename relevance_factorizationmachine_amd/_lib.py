@@ -120,6 +120,7 @@ SIGNATURES = {
     "rfm_fm_plan_info": [_vp, _vp],
     "rfm_fm_plan_layout": [_vp, _vp],
     "rfm_fm_plan_sliced": [_vp, _vp],
+    "rfm_fm_plan_register_validation": [_vp, _vp, _vp, _vp, _vp, _i64],
     "rfm_fm_plan_hot_columns": [_vp, _vp, _i32],
     "rfm_fm_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f64],
     "rfm_fm_grad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],

@@ -949,7 +949,10 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
     // logarithms: the two logs of a row's term are ~200 dependent f64 instructions, and a whole
     // run of iterations' terms are computed by one launch instead (RFM_DEFER_LOSS=0: in the
     // forward, staged through LDS).
-    const bool scores_only = !sliced.ok && !merge_call && sl_a + sl_b > 0 && env_int("RFM_DEFER_LOSS", 1) != 0;
+    // (a call of a few iterations -- a fit() with a host evaluator trains one per call -- would only
+    // add the run's launches)
+    const bool scores_only = !sliced.ok && !merge_call && sl_a + sl_b > 0 && n_iters >= 4 &&
+                             env_int("RFM_DEFER_LOSS", 1) != 0;
     const bool deferred = sliced.ok || scores_only;
     const int zns = sliced.ok ? plan->sl_ns : 0;  // (0: the buffer holds scores)
     int64_t run_len = kRun;
@@ -959,8 +962,13 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
       run_len = std::min(run_len, n_iters);
       plan->sl_z.ensure(size_t(run_len) * size_t(z_per_iter) * 8);
       // (the validation log is only known here: translated once per call)
-      if (sliced.ok && sl_b > 0)
+      // (... unless the caller has registered these arrays: rfm_fm_plan_register_validation)
+      const bool registered = plan->sl_val_rows == sl_b && plan->sl_val_indptr == d_val_indptr &&
+                              plan->sl_val_indices == d_val_indices && plan->sl_val_values == d_val_values;
+      if (sliced.ok && sl_b > 0 && !registered) {
+        plan->sl_val_rows = -1;  // (sl_val is about to hold another log)
         sliced_translate(ctx, plan, d_val_indptr, d_val_indices, d_val_values, sl_b, plan->sl_val);
+      }
     }
 #ifdef RFM_SLICED_STAMPS
     DevBuf stamps;

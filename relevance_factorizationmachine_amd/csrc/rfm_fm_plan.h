@@ -32,7 +32,13 @@ struct rfm_fm_plan {
   rfm::DevBuf sl_cols, sl_rank;
   rfm::DevBuf sl_train;  // the training log translated (rows of 2^sl_ml_log2 SlEnt records)
   rfm::DevBuf sl_pad;    // one padding record
-  rfm::DevBuf sl_val;    // ... the validation log of the current rfm_fm_train call
+  rfm::DevBuf sl_val;    // ... the validation log of the current rfm_fm_train call, or the registered one
+  // rfm_fm_plan_register_validation: the arrays sl_val was translated from (rfm_fm_train calls
+  // that name the same arrays skip the translation -- a fit() that trains one iteration per call)
+  const void* sl_val_indptr = nullptr;
+  const void* sl_val_indices = nullptr;
+  const void* sl_val_values = nullptr;
+  int64_t sl_val_rows = -1;
   rfm::DevBuf sl_z;      // partial logits [iterations of a run][slices][rows]
   std::vector<int32_t> h_hot_cols;  // host copy of hot_cols (rfm_fm_plan_hot_columns)
   // touched-row gradients (rfm_fm_grad_rows), allocated on first use: the gradient table

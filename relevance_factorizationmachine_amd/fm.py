@@ -214,6 +214,10 @@ class FactorizationMachines(PointwiseBaseRecommender):
         plan = (plan_cache(rt).take(rt, tr, y, p, self.n_factors, self.batch_size, hot) if keep
                 else FmPlan(rt, tr, y, p, self.n_factors, self.batch_size, hot))
         self.plan_info = dict(plan.info(), **plan.layout(), **plan.sliced())  # (what the last fit trained with)
+        if va.shape[0] > 0:  # (the split's device copy does not change during this fit)
+            _lib.check(rt.lib.rfm_fm_plan_register_validation(
+                rt.ctx, plan.handle, va.indptr.data_ptr(), va.indices.data_ptr(), va.values.data_ptr(),
+                va.shape[0]))
         tl = rt.empty((self.n_epochs,), y.dtype)
         vl = rt.empty((self.n_epochs,), y.dtype)
         # an empty validation set: the reference's mean over no rows is nan (src/base.py:61)
@@ -276,6 +280,8 @@ class FactorizationMachines(PointwiseBaseRecommender):
             rt.sync()
         finally:
             rt.sync()
+            # (the registration ends with the fit: the plan may outlive this split's device copy)
+            rt.lib.rfm_fm_plan_register_validation(rt.ctx, plan.handle, None, None, None, 0)
             if keep:
                 plan_cache(rt).give_back(plan)
             else:

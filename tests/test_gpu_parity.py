@@ -1221,3 +1221,67 @@ def test_deferred_loss_logarithms_give_the_same_losses(rfm, monkeypatch, shape, 
     n_ref = min(its, 8)
     ref = cpu_ref.fm_fit(train, val, n_epochs=n_ref, n_factors=k, lr=9e-6, batch_size=batch, seed=12345)
     assert rel_err(trb[:n_ref], ref["train_loss"]) < TIGHT and rel_err(vab[:n_ref], ref["val_loss"]) < TIGHT
+
+
+def test_sliced_loss_forward_one_iteration_per_call_and_registration(rfm, monkeypatch):
+    """A fit() with a host evaluator trains one iteration per rfm_fm_train call: the sliced loss
+    forward then reads the validation log that fit() REGISTERED with the plan
+    (rfm_fm_plan_register_validation: translated once, not per call) and must give the losses of the
+    plain many-iterations-per-call fit bit for bit; a call that names other validation arrays than
+    the registered ones is translated per call and is right as well."""
+    pkg, _lib, runtime, rt = rfm
+    from relevance_factorizationmachine_amd.fm import FmPlan
+    rng = np.random.default_rng(11)
+    train = _random_log(rng, 3000, 200, 0.05, 4)
+    val = _random_log(rng, 700, 200, 0.05, 4)
+    other = _random_log(rng, 500, 200, 0.05, 4)
+    monkeypatch.setenv("RFM_SLICED_MIN_ROWS", "1")
+
+    class Mean:
+        features = {"FM": val["features"]}
+
+        def evaluate(self, y_scores, estimator):
+            return float(np.mean(y_scores))
+
+    kw = dict(n_factors=300, n_features=200, lr=2e-6, batch_size=1000, n_epochs=5, seed=5)
+    base = _fm(pkg, **kw)
+    base.hot_min_count = -1
+    tr0, va0 = base.fit(train, val)
+    m = _fm(pkg, evaluator=Mean(), **kw)
+    m.hot_min_count = -1
+    m.device_evaluator = False
+    tr1, va1 = m.fit(train, val)
+    np.testing.assert_array_equal(np.asarray(tr1), np.asarray(tr0))
+    np.testing.assert_array_equal(np.asarray(va1), np.asarray(va0))
+    np.testing.assert_array_equal(m.V(), base.V())
+    assert len(m.val_metrics) == 5
+    # through the C ABI: the plan holds `val` registered, the call names `other`
+    dev = runtime.DeviceCSR(rt, train["features"])
+    y = rt.upload(train["labels"], dtype=np.float64)
+    p = rt.upload(train["pscores"], dtype=np.float64)
+    dv = runtime.DeviceCSR(rt, val["features"])
+    do = runtime.DeviceCSR(rt, other["features"])
+    oy = rt.upload(other["labels"], dtype=np.float64)
+    op = rt.upload(other["pscores"], dtype=np.float64)
+    ids = rt.upload(runtime.sample_batches(3000, 1000, 0, 5))
+    out = {}
+    for registered in (False, True):
+        plan = FmPlan(rt, dev, y, p, 300, 1000, -1)
+        if registered:
+            _lib.check(rt.lib.rfm_fm_plan_register_validation(
+                rt.ctx, plan.handle, dv.indptr.data_ptr(), dv.indices.data_ptr(), dv.values.data_ptr(), 700))
+        mm = _fm(pkg, **kw)
+        tl = rt.empty((5,), y.dtype)
+        vl = rt.empty((5,), y.dtype)
+        _lib.check(rt.lib.rfm_fm_train(
+            rt.ctx, plan.handle, dev.indptr.data_ptr(), dev.indices.data_ptr(), dev.values.data_ptr(),
+            y.data_ptr(), p.data_ptr(), ids.data_ptr(), 1000, 5, mm.w0.dev.data_ptr(), mm.w.dev.data_ptr(),
+            mm.V.dev.data_ptr(), 2e-6, do.indptr.data_ptr(), do.indices.data_ptr(), do.values.data_ptr(),
+            oy.data_ptr(), op.data_ptr(), 500, 1e-8, tl.data_ptr(), vl.data_ptr()))
+        rt.sync()
+        out[registered] = vl.cpu().numpy()
+        plan.close()
+    monkeypatch.delenv("RFM_SLICED_MIN_ROWS")
+    np.testing.assert_array_equal(out[True], out[False])
+    ref = cpu_ref.fm_fit(train, other, n_epochs=5, n_factors=300, lr=2e-6, batch_size=1000, seed=5)
+    assert rel_err(out[True], ref["val_loss"]) < TIGHT

@@ -173,14 +173,23 @@ int32_t rfm_fm_plan_layout(const rfm_fm_plan* plan, int32_t* h_out4);
  * the factors (0: this plan has none), [1]=factors per slice, [2]=columns whose slice a workgroup
  * keeps in LDS, [3]=records per row of the translated logs */
 int32_t rfm_fm_plan_sliced(const rfm_fm_plan* plan, int32_t* h_out4);
-/* Optional: the validation log that coming rfm_fm_train calls on this plan will name (device CSR
- * arrays).  A plan with sliced loss forwards keeps its translated form, and calls that pass the SAME
- * three pointers and row count skip the per-call translation (a fit() that trains one iteration per
- * call).  The caller promises that the arrays do not change until it registers again; any other
- * arrays are translated per call as before. */
-int32_t rfm_fm_plan_register_validation(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
-                                        const int32_t* d_indices, const double* d_values,
-                                        int64_t n_rows);
+/* Optional: a log that coming calls on this plan will name (device CSR arrays): slot 0 = the
+ * validation log of rfm_fm_train, slot 1 = the log rfm_fm_plan_forward scores.  A plan with sliced
+ * loss forwards keeps the log's translated form, and calls that pass the SAME three pointers and row
+ * count skip the per-call translation (a fit() that trains one iteration per call and scores an
+ * evaluation log after each).  The caller promises that the arrays do not change until it registers
+ * the slot again (n_rows = 0: nothing); any other arrays are translated per call. */
+int32_t rfm_fm_plan_register_log(rfm_ctx* ctx, rfm_fm_plan* plan, int32_t slot, const int64_t* d_indptr,
+                                 const int32_t* d_indices, const double* d_values, int64_t n_rows);
+/* rfm_fm_forward through the plan: scores of the rows of a CSR with the plan's column count, by the
+ * sliced forward (rfm_fm_train's loss forward, even factor counts above 128) when the plan has one
+ * and the rows are enough for it, else by the plain forward -- the same scores up to the order of
+ * the sums.  Replaces src/fm.py:114-133 inside a fit() that scores an evaluation log every
+ * iteration (utils/search_params.py:96-111). */
+int32_t rfm_fm_plan_forward(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
+                            const int32_t* d_indices, const double* d_values, int64_t n_rows,
+                            const double* d_w0, const double* d_w, const double* d_V,
+                            double* d_out_pred);
 /* the hot columns (ascending), h_out[0 .. info[2]); capacity = room in h_out */
 int32_t rfm_fm_plan_hot_columns(const rfm_fm_plan* plan, int32_t* h_out, int32_t capacity);
 
@@ -285,6 +294,28 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
                      const double* d_val_values, const double* d_val_y,
                      const double* d_val_pscore, int64_t n_val, double eps,
                      double* d_out_train_loss, double* d_out_val_loss);
+/* rfm_fm_train with the evaluator hook of the reference's search loop inside
+ * (utils/search_params.py:96-111: fit(..., evaluator=ValEvaluator) -- after every iteration the
+ * scores of the evaluation log, src/fm.py:104-110, and their IPS-DCG@k, utils/evaluate.py:160-207):
+ * iteration i of the call leaves the scores of the n_ev rows of the evaluation CSR in
+ * d_scores + (slot_first + i) * scores_stride (through rfm_fm_plan_forward), the per-group values
+ * of rfm_val_dcg in d_user_scratch + (slot_first + i) * user_stride (>= 3 * n_segments doubles) and
+ * its two results in d_dcg_out[2 i], [2 i + 1].  d_seg_ptr / d_rows / d_labels / d_ev_pscores /
+ * n_segments / k: as rfm_val_dcg.  One enqueue for the whole run of iterations; nothing synchronises. */
+int32_t rfm_fm_train_eval(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
+                          const int32_t* d_indices, const double* d_values, const double* d_y,
+                          const double* d_pscore, const int32_t* d_ids, int64_t batch,
+                          int64_t n_iters, double* d_w0, double* d_w, double* d_V, double lr,
+                          const int64_t* d_val_indptr, const int32_t* d_val_indices,
+                          const double* d_val_values, const double* d_val_y,
+                          const double* d_val_pscore, int64_t n_val, double eps,
+                          double* d_out_train_loss, double* d_out_val_loss,
+                          const int64_t* d_ev_indptr, const int32_t* d_ev_indices,
+                          const double* d_ev_values, int64_t n_ev, const int32_t* d_seg_ptr,
+                          const int32_t* d_rows, const double* d_labels, const double* d_ev_pscores,
+                          int32_t n_segments, int32_t k, double* d_scores, int64_t scores_stride,
+                          double* d_user_scratch, int64_t user_stride, int64_t slot_first,
+                          double* d_dcg_out);
 
 /* ---- FM: the data-parallel fit() loop ------------------------
  * The reference has no multi-process mode; this is the body of FactorizationMachines.fit

@@ -120,7 +120,8 @@ SIGNATURES = {
     "rfm_fm_plan_info": [_vp, _vp],
     "rfm_fm_plan_layout": [_vp, _vp],
     "rfm_fm_plan_sliced": [_vp, _vp],
-    "rfm_fm_plan_register_validation": [_vp, _vp, _vp, _vp, _vp, _i64],
+    "rfm_fm_plan_register_log": [_vp, _vp, _i32, _vp, _vp, _vp, _i64],
+    "rfm_fm_plan_forward": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "rfm_fm_plan_hot_columns": [_vp, _vp, _i32],
     "rfm_fm_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f64],
     "rfm_fm_grad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
@@ -131,6 +132,9 @@ SIGNATURES = {
     "rfm_fm_set_rows": [_vp, _vp, _i64, _vp, _i32, _i64, _vp, _vp, _vp, _i64, _i32, _f64],
     "rfm_fm_train": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _f64,
                      _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp],
+    "rfm_fm_train_eval": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _f64,
+                     _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp,
+                          _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _i64, _vp],
     "rfm_fm_train_dp": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f64, _vp],
     "rfm_fm_fit_dp": [_vp, _vp, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp,
                       _i64, _f64, _vp, _vp],

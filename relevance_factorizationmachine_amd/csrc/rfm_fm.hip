@@ -900,6 +900,90 @@ int32_t rfm_fm_train_dp(rfm_ctx* ctx, rfm_fm_plan* plan, const int32_t* d_ids,
   });
 }
 
+}  // extern "C"
+
+namespace {
+
+// scores of the rows of a CSR through the plan (rfm_fm_plan_forward): the sliced forward where
+// the plan has one and the rows are enough for it, else the plain one
+void plan_forward(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr, const int32_t* d_indices,
+                  const double* d_values, int64_t n_rows, const double* d_w0, const double* d_w,
+                  const double* d_V, double* d_out_pred) {
+  if (n_rows == 0) return;
+  const SlicedGeom sliced = sliced_geom(ctx, plan, n_rows);
+  if (!sliced.ok) {  // the plain forward (rfm_fm_forward)
+    FwdArgs f = forward_args(d_indptr, d_indices, d_values, nullptr, n_rows, d_w0, d_w, d_V, plan->k);
+    f.out_pred = d_out_pred;
+    launch_forward(ctx, f);
+    return;
+  }
+  rfm_fm_plan::SlLog& log = plan->sl_log[1];
+  if (!log.holds(d_indptr, d_indices, d_values, n_rows)) {
+    log.rows = -1;
+    sliced_translate(ctx, plan, d_indptr, d_indices, d_values, n_rows, log.tr);
+  }
+  plan->sl_zf.ensure(size_t(plan->sl_ns) * size_t(n_rows) * 8);
+  SlicedArgs f{};
+  f.tr_a = plan->sl_train.as<SlEnt>();
+  f.tr_b = log.tr.as<SlEnt>();
+  f.pad = plan->sl_pad.as<SlEnt>();
+  f.indptr_b = d_indptr;
+  f.indices_b = d_indices;
+  f.values_b = d_values;
+  f.n_b = n_rows;
+  f.w0 = d_w0;
+  f.w = d_w;
+  f.V = d_V;
+  f.zpart = plan->sl_zf.as<double>();
+  launch_sliced(ctx, plan, sliced, f);
+  const int grid = int(std::min<int64_t>((n_rows + kBlock - 1) / kBlock, int64_t(ctx->n_cu) * 8));
+  hipLaunchKernelGGL(scores_from_slices_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream,
+                     plan->sl_zf.as<double>(), plan->sl_ns, n_rows, d_out_pred);
+  RFM_HIP_CHECK(hipGetLastError());
+}
+
+// what a fit() loop with a ValEvaluator does after every iteration (utils/search_params.py:96-111,
+// utils/evaluate.py:160-207): score the evaluation log, take its IPS-DCG@k (rfm_val_dcg)
+struct EvalHook {
+  const int64_t* indptr;
+  const int32_t* indices;
+  const double* values;
+  int64_t n_rows;
+  const int32_t* seg_ptr;
+  const int32_t* rows;
+  const double* labels;
+  const double* pscores;
+  int32_t n_segments, k;
+  double* scores;        // [n_slots][scores_stride]; iteration i of the call -> slot slot_first + i
+  int64_t scores_stride;
+  double* user_scratch;  // [n_slots][user_stride]
+  int64_t user_stride;
+  int64_t slot_first;
+  double* dcg_out;       // [n_iters][2]
+};
+
+void train_loop(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr, const int32_t* d_indices,
+                const double* d_values, const double* d_y, const double* d_pscore, const int32_t* d_ids,
+                int64_t batch, int64_t n_iters, double* d_w0, double* d_w, double* d_V, double lr,
+                const int64_t* d_val_indptr, const int32_t* d_val_indices, const double* d_val_values,
+                const double* d_val_y, const double* d_val_pscore, int64_t n_val, double eps,
+                double* d_out_train_loss, double* d_out_val_loss, const EvalHook* hook);
+
+}  // namespace
+
+extern "C" {
+
+int32_t rfm_fm_plan_forward(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
+                            const int32_t* d_indices, const double* d_values, int64_t n_rows,
+                            const double* d_w0, const double* d_w, const double* d_V,
+                            double* d_out_pred) {
+  return guarded([&] {
+    RFM_REQUIRE(ctx && plan && d_indptr && d_w0 && d_w && d_V && d_out_pred, "null pointer");
+    RFM_REQUIRE(n_rows >= 0, "negative n_rows");
+    plan_forward(ctx, plan, d_indptr, d_indices, d_values, n_rows, d_w0, d_w, d_V, d_out_pred);
+  });
+}
+
 int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
                      const int32_t* d_indices, const double* d_values, const double* d_y,
                      const double* d_pscore, const int32_t* d_ids, int64_t batch,
@@ -909,6 +993,51 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
                      const double* d_val_pscore, int64_t n_val, double eps,
                      double* d_out_train_loss, double* d_out_val_loss) {
   return guarded([&] {
+    train_loop(ctx, plan, d_indptr, d_indices, d_values, d_y, d_pscore, d_ids, batch, n_iters, d_w0, d_w,
+               d_V, lr, d_val_indptr, d_val_indices, d_val_values, d_val_y, d_val_pscore, n_val, eps,
+               d_out_train_loss, d_out_val_loss, nullptr);
+  });
+}
+
+int32_t rfm_fm_train_eval(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
+                          const int32_t* d_indices, const double* d_values, const double* d_y,
+                          const double* d_pscore, const int32_t* d_ids, int64_t batch,
+                          int64_t n_iters, double* d_w0, double* d_w, double* d_V, double lr,
+                          const int64_t* d_val_indptr, const int32_t* d_val_indices,
+                          const double* d_val_values, const double* d_val_y,
+                          const double* d_val_pscore, int64_t n_val, double eps,
+                          double* d_out_train_loss, double* d_out_val_loss,
+                          const int64_t* d_ev_indptr, const int32_t* d_ev_indices,
+                          const double* d_ev_values, int64_t n_ev, const int32_t* d_seg_ptr,
+                          const int32_t* d_rows, const double* d_labels, const double* d_ev_pscores,
+                          int32_t n_segments, int32_t k, double* d_scores, int64_t scores_stride,
+                          double* d_user_scratch, int64_t user_stride, int64_t slot_first,
+                          double* d_dcg_out) {
+  return guarded([&] {
+    RFM_REQUIRE(d_ev_indptr && d_seg_ptr && d_rows && d_labels && d_scores && d_user_scratch && d_dcg_out,
+                "null pointer (evaluation)");
+    RFM_REQUIRE(n_ev >= 1 && scores_stride >= n_ev && user_stride >= 3 * int64_t(n_segments) && slot_first >= 0,
+                "bad evaluation shape");
+    const EvalHook hook{d_ev_indptr, d_ev_indices, d_ev_values, n_ev, d_seg_ptr, d_rows, d_labels,
+                        d_ev_pscores, n_segments, k, d_scores, scores_stride, d_user_scratch, user_stride,
+                        slot_first, d_dcg_out};
+    train_loop(ctx, plan, d_indptr, d_indices, d_values, d_y, d_pscore, d_ids, batch, n_iters, d_w0, d_w,
+               d_V, lr, d_val_indptr, d_val_indices, d_val_values, d_val_y, d_val_pscore, n_val, eps,
+               d_out_train_loss, d_out_val_loss, &hook);
+  });
+}
+
+}  // extern "C"
+
+namespace {
+
+void train_loop(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr, const int32_t* d_indices,
+                const double* d_values, const double* d_y, const double* d_pscore, const int32_t* d_ids,
+                int64_t batch, int64_t n_iters, double* d_w0, double* d_w, double* d_V, double lr,
+                const int64_t* d_val_indptr, const int32_t* d_val_indices, const double* d_val_values,
+                const double* d_val_y, const double* d_val_pscore, int64_t n_val, double eps,
+                double* d_out_train_loss, double* d_out_val_loss, const EvalHook* hook) {
+  {
     RFM_REQUIRE(ctx && d_w0 && d_w && d_V, "null pointer");
     RFM_REQUIRE(n_iters >= 0, "negative n_iters");
     if (n_iters == 0) return;
@@ -962,12 +1091,10 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
       run_len = std::min(run_len, n_iters);
       plan->sl_z.ensure(size_t(run_len) * size_t(z_per_iter) * 8);
       // (the validation log is only known here: translated once per call)
-      // (... unless the caller has registered these arrays: rfm_fm_plan_register_validation)
-      const bool registered = plan->sl_val_rows == sl_b && plan->sl_val_indptr == d_val_indptr &&
-                              plan->sl_val_indices == d_val_indices && plan->sl_val_values == d_val_values;
-      if (sliced.ok && sl_b > 0 && !registered) {
-        plan->sl_val_rows = -1;  // (sl_val is about to hold another log)
-        sliced_translate(ctx, plan, d_val_indptr, d_val_indices, d_val_values, sl_b, plan->sl_val);
+      // (... unless the caller has registered these arrays: rfm_fm_plan_register_log, slot 0)
+      if (sliced.ok && sl_b > 0 && !plan->sl_log[0].holds(d_val_indptr, d_val_indices, d_val_values, sl_b)) {
+        plan->sl_log[0].rows = -1;  // (the slot is about to hold another log)
+        sliced_translate(ctx, plan, d_val_indptr, d_val_indices, d_val_values, sl_b, plan->sl_log[0].tr);
       }
     }
 #ifdef RFM_SLICED_STAMPS
@@ -1036,7 +1163,7 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
       if (sliced.ok) {
         SlicedArgs f{};
         f.tr_a = plan->sl_train.as<SlEnt>();
-        f.tr_b = plan->sl_val.as<SlEnt>();
+        f.tr_b = plan->sl_log[0].tr.as<SlEnt>();
         f.pad = plan->sl_pad.as<SlEnt>();
         f.indptr_a = d_indptr;
         f.indices_a = d_indices;
@@ -1109,6 +1236,15 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
           val_parts = forward_loss_deferred(ctx, f, val_rows + slot * kMaxFwdGrid);
         }
       }
+      if (hook) {  // the evaluator's scores and their IPS-DCG@k, this iteration's parameters
+        double* sc = hook->scores + (hook->slot_first + it) * hook->scores_stride;
+        plan_forward(ctx, plan, hook->indptr, hook->indices, hook->values, hook->n_rows, d_w0, d_w, d_V, sc);
+        const int32_t rc = rfm_val_dcg(ctx, sc, hook->seg_ptr, hook->rows, hook->labels, hook->pscores,
+                                       hook->n_segments, hook->k,
+                                       hook->user_scratch + (hook->slot_first + it) * hook->user_stride,
+                                       hook->dcg_out + 2 * it);
+        if (rc != RFM_OK) throw Error(rc, "the evaluator's DCG failed (see above)");
+      }
       if (slot + 1 == run_len) {
         if (ride && it + 1 < n_iters) {  // (its last train scores arrive with the next step)
           pending_first = run_first;
@@ -1140,7 +1276,7 @@ int32_t rfm_fm_train(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
       }
     }
 #endif
-  });
+  }
 }
 
-}  // extern "C"
+}  // namespace

@@ -32,14 +32,22 @@ struct rfm_fm_plan {
   rfm::DevBuf sl_cols, sl_rank;
   rfm::DevBuf sl_train;  // the training log translated (rows of 2^sl_ml_log2 SlEnt records)
   rfm::DevBuf sl_pad;    // one padding record
-  rfm::DevBuf sl_val;    // ... the validation log of the current rfm_fm_train call, or the registered one
-  // rfm_fm_plan_register_validation: the arrays sl_val was translated from (rfm_fm_train calls
-  // that name the same arrays skip the translation -- a fit() that trains one iteration per call)
-  const void* sl_val_indptr = nullptr;
-  const void* sl_val_indices = nullptr;
-  const void* sl_val_values = nullptr;
-  int64_t sl_val_rows = -1;
+  // ... of the validation log of the current rfm_fm_train call (slot 0) and of the log that
+  // rfm_fm_plan_forward scores (slot 1).  rfm_fm_plan_register_log: the arrays a slot was
+  // translated from -- calls that name the same arrays skip the translation (a fit() that trains
+  // one iteration per call and scores an evaluation log after each)
+  struct SlLog {
+    rfm::DevBuf tr;
+    const void* indptr = nullptr;
+    const void* indices = nullptr;
+    const void* values = nullptr;
+    int64_t rows = -1;  // -1: nothing registered
+    bool holds(const void* ip, const void* ix, const void* v, int64_t n) const {
+      return rows == n && indptr == ip && indices == ix && values == v;
+    }
+  } sl_log[2];
   rfm::DevBuf sl_z;      // partial logits [iterations of a run][slices][rows]
+  rfm::DevBuf sl_zf;     // ... of rfm_fm_plan_forward's rows
   std::vector<int32_t> h_hot_cols;  // host copy of hot_cols (rfm_fm_plan_hot_columns)
   // touched-row gradients (rfm_fm_grad_rows), allocated on first use: the gradient table
   // [G_V | g_w | g_w0] indexed by column, never cleared; touch[col] == touch_seq marks the
@@ -73,7 +81,8 @@ struct rfm_fm_plan {
   size_t device_bytes() const {
     return ell.bytes + ell_yp.bytes + ent.bytes + rows.bytes + slot_t.bytes + slot_bits.bytes + slots.bytes + tasks.bytes +
            split.bytes + parts.bytes + Q.bytes + err.bytes + hot_cols.bytes + hot_slab.bytes +
-           err_partial.bytes + sl_cols.bytes + sl_rank.bytes + sl_train.bytes + sl_val.bytes + sl_z.bytes;
+           err_partial.bytes + sl_cols.bytes + sl_rank.bytes + sl_train.bytes + sl_log[0].tr.bytes +
+           sl_log[1].tr.bytes + sl_z.bytes + sl_zf.bytes;
   }
 };
 

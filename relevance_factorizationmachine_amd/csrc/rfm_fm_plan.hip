@@ -581,18 +581,18 @@ int32_t rfm_fm_plan_info(const rfm_fm_plan* plan, int64_t* h_out8) {
   });
 }
 
-int32_t rfm_fm_plan_register_validation(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
-                                        const int32_t* d_indices, const double* d_values,
-                                        int64_t n_rows) {
+int32_t rfm_fm_plan_register_log(rfm_ctx* ctx, rfm_fm_plan* plan, int32_t slot, const int64_t* d_indptr,
+                                 const int32_t* d_indices, const double* d_values, int64_t n_rows) {
   return guarded([&] {
-    RFM_REQUIRE(ctx && plan, "null pointer");
-    plan->sl_val_rows = -1;
+    RFM_REQUIRE(ctx && plan && (slot == 0 || slot == 1), "null pointer / slot outside 0..1");
+    rfm_fm_plan::SlLog& log = plan->sl_log[slot];
+    log.rows = -1;
     if (plan->sl_ns <= 0 || n_rows <= 0 || !d_indptr) return;  // (nothing to keep)
-    sliced_translate(ctx, plan, d_indptr, d_indices, d_values, n_rows, plan->sl_val);
-    plan->sl_val_indptr = d_indptr;
-    plan->sl_val_indices = d_indices;
-    plan->sl_val_values = d_values;
-    plan->sl_val_rows = n_rows;
+    sliced_translate(ctx, plan, d_indptr, d_indices, d_values, n_rows, log.tr);
+    log.indptr = d_indptr;
+    log.indices = d_indices;
+    log.values = d_values;
+    log.rows = n_rows;
   });
 }
 

@@ -410,4 +410,14 @@ __global__ __launch_bounds__(kBlock) void loss_from_slices_kernel(
   if (threadIdx.x == 0) partial[int64_t(blockIdx.y) * partial_stride + blockIdx.x] = s;
 }
 
+// scores of rows from their partial logits (rfm_fm_plan_forward)
+__global__ __launch_bounds__(kBlock) void scores_from_slices_kernel(const double* z, int ns, int64_t nr,
+                                                                  double* out) {
+  for (int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x; t < nr; t += int64_t(gridDim.x) * kBlock) {
+    double zz = z[t];
+    for (int s = 1; s < ns; ++s) zz += z[int64_t(s) * nr + t];
+    out[t] = sigmoid_clipped(zz);
+  }
+}
+
 }  // namespace rfm

@@ -206,6 +206,16 @@ class EvalLoop:
         if (epoch + 1) % self.chunk == 0:
             self._flush(epoch + 1)
 
+    def room(self, epoch: int) -> int:
+        """Iterations from ``epoch`` on that fit the current chunk of score slots."""
+        return self.chunk - epoch % self.chunk
+
+    def ran(self, first: int, count: int) -> None:
+        """Iterations ``first .. first + count`` (inside one chunk: ``count <= room(first)``) were
+        scored and measured by the library itself (``rfm_fm_train_eval``)."""
+        if (first + count) % self.chunk == 0:
+            self._flush(first + count)
+
     def _flush(self, upto: int) -> None:
         if upto <= self._flushed:
             return

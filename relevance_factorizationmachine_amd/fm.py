@@ -215,8 +215,8 @@ class FactorizationMachines(PointwiseBaseRecommender):
                 else FmPlan(rt, tr, y, p, self.n_factors, self.batch_size, hot))
         self.plan_info = dict(plan.info(), **plan.layout(), **plan.sliced())  # (what the last fit trained with)
         if va.shape[0] > 0:  # (the split's device copy does not change during this fit)
-            _lib.check(rt.lib.rfm_fm_plan_register_validation(
-                rt.ctx, plan.handle, va.indptr.data_ptr(), va.indices.data_ptr(), va.values.data_ptr(),
+            _lib.check(rt.lib.rfm_fm_plan_register_log(
+                rt.ctx, plan.handle, 0, va.indptr.data_ptr(), va.indices.data_ptr(), va.values.data_ptr(),
                 va.shape[0]))
         tl = rt.empty((self.n_epochs,), y.dtype)
         vl = rt.empty((self.n_epochs,), y.dtype)
@@ -227,15 +227,24 @@ class FactorizationMachines(PointwiseBaseRecommender):
 
         chunk = {"first": 0, "ids": None}
 
-        def run(first: int, count: int) -> None:
+        def run(first: int, count: int, loop=None) -> None:
             ids_ptr = chunk["ids"].data_ptr() + (first - chunk["first"]) * self.batch_size * 4
-            _lib.check(rt.lib.rfm_fm_train(
-                rt.ctx, plan.handle, tr.indptr.data_ptr(), tr.indices.data_ptr(), tr.values.data_ptr(),
-                y.data_ptr(), p.data_ptr(), ids_ptr, self.batch_size, count,
-                self.w0.dev.data_ptr(), self.w.dev.data_ptr(), self.V.dev.data_ptr(), float(self.lr),
-                va.indptr.data_ptr(), va.indices.data_ptr(), va.values.data_ptr(),
-                vy.data_ptr(), vp.data_ptr(), va.shape[0], LOSS_EPS,
-                tl.data_ptr() + first * 8, vl.data_ptr() + first * 8 if has_val else None))
+            args = (rt.ctx, plan.handle, tr.indptr.data_ptr(), tr.indices.data_ptr(), tr.values.data_ptr(),
+                    y.data_ptr(), p.data_ptr(), ids_ptr, self.batch_size, count,
+                    self.w0.dev.data_ptr(), self.w.dev.data_ptr(), self.V.dev.data_ptr(), float(self.lr),
+                    va.indptr.data_ptr(), va.indices.data_ptr(), va.values.data_ptr(),
+                    vy.data_ptr(), vp.data_ptr(), va.shape[0], LOSS_EPS,
+                    tl.data_ptr() + first * 8, vl.data_ptr() + first * 8 if has_val else None)
+            if loop is None:
+                _lib.check(rt.lib.rfm_fm_train(*args))
+                return
+            fr = loop.frame
+            _lib.check(rt.lib.rfm_fm_train_eval(
+                *args, ev.indptr.data_ptr(), ev.indices.data_ptr(), ev.values.data_ptr(), ev.shape[0],
+                fr.seg_ptr.data_ptr(), fr.rows.data_ptr(), fr.labels.data_ptr(),
+                None if fr.pscores is None else fr.pscores.data_ptr(), fr.n_segments, fr.k,
+                loop.scores.data_ptr(), loop.scores.shape[1], loop.users.data_ptr(), loop.users.shape[1],
+                first % loop.chunk, loop.out.data_ptr() + first * 16))
 
         try:
             frame = loop = ev = ev_X = None
@@ -250,6 +259,9 @@ class FactorizationMachines(PointwiseBaseRecommender):
                         raise ValueError(
                             f"X has {ev_X.shape[1]} columns, model has {self.n_features}")
                     ev = self._csr_cache.get(ev_X)
+                    _lib.check(rt.lib.rfm_fm_plan_register_log(
+                        rt.ctx, plan.handle, 1, ev.indptr.data_ptr(), ev.indices.data_ptr(),
+                        ev.values.data_ptr(), ev.shape[0]))
                     loop = EvalLoop(rt, frame, self.evaluator, self.estimator, self.n_epochs)
             for first, host_ids, dev_ids in id_stream.chunks():
                 chunk["first"], chunk["ids"] = first, dev_ids
@@ -264,14 +276,15 @@ class FactorizationMachines(PointwiseBaseRecommender):
                         self.val_metrics.append(
                             self.evaluator.evaluate(y_scores=y_scores, estimator=self.estimator))
                 else:
-                    for epoch in range(first, first + count):
-                        run(epoch, 1)
-                        _lib.check(rt.lib.rfm_fm_forward(
-                            rt.ctx, ev.indptr.data_ptr(), ev.indices.data_ptr(), ev.values.data_ptr(),
-                            None, ev.shape[0], self.w0.dev.data_ptr(), self.w.dev.data_ptr(),
-                            self.V.dev.data_ptr(), self.n_features, self.n_factors,
-                            loop.slot(epoch).data_ptr()))
-                        loop.done(epoch)
+                    # the recognised evaluator: scores + IPS-DCG@k inside the library's loop
+                    # (rfm_fm_train_eval), one enqueue per run of iterations that fits the chunk
+                    # of score slots
+                    at = first
+                    while at < first + count:
+                        n = min(first + count - at, loop.room(at))
+                        run(at, n, loop)
+                        loop.ran(at, n)
+                        at += n
             if loop is not None:
                 self.val_metrics.extend(loop.finish(self.n_epochs))
                 self.evaluator_host_calls = loop.host_calls
@@ -281,7 +294,8 @@ class FactorizationMachines(PointwiseBaseRecommender):
         finally:
             rt.sync()
             # (the registration ends with the fit: the plan may outlive this split's device copy)
-            rt.lib.rfm_fm_plan_register_validation(rt.ctx, plan.handle, None, None, None, 0)
+            for log_slot in (0, 1):
+                rt.lib.rfm_fm_plan_register_log(rt.ctx, plan.handle, log_slot, None, None, None, 0)
             if keep:
                 plan_cache(rt).give_back(plan)
             else:

@@ -1226,7 +1226,7 @@ def test_deferred_loss_logarithms_give_the_same_losses(rfm, monkeypatch, shape, 
 def test_sliced_loss_forward_one_iteration_per_call_and_registration(rfm, monkeypatch):
     """A fit() with a host evaluator trains one iteration per rfm_fm_train call: the sliced loss
     forward then reads the validation log that fit() REGISTERED with the plan
-    (rfm_fm_plan_register_validation: translated once, not per call) and must give the losses of the
+    (rfm_fm_plan_register_log: translated once, not per call) and must give the losses of the
     plain many-iterations-per-call fit bit for bit; a call that names other validation arrays than
     the registered ones is translated per call and is right as well."""
     pkg, _lib, runtime, rt = rfm
@@ -1268,8 +1268,8 @@ def test_sliced_loss_forward_one_iteration_per_call_and_registration(rfm, monkey
     for registered in (False, True):
         plan = FmPlan(rt, dev, y, p, 300, 1000, -1)
         if registered:
-            _lib.check(rt.lib.rfm_fm_plan_register_validation(
-                rt.ctx, plan.handle, dv.indptr.data_ptr(), dv.indices.data_ptr(), dv.values.data_ptr(), 700))
+            _lib.check(rt.lib.rfm_fm_plan_register_log(
+                rt.ctx, plan.handle, 0, dv.indptr.data_ptr(), dv.indices.data_ptr(), dv.values.data_ptr(), 700))
         mm = _fm(pkg, **kw)
         tl = rt.empty((5,), y.dtype)
         vl = rt.empty((5,), y.dtype)
@@ -1285,3 +1285,47 @@ def test_sliced_loss_forward_one_iteration_per_call_and_registration(rfm, monkey
     np.testing.assert_array_equal(out[True], out[False])
     ref = cpu_ref.fm_fit(train, other, n_epochs=5, n_factors=300, lr=2e-6, batch_size=1000, seed=5)
     assert rel_err(out[True], ref["val_loss"]) < TIGHT
+
+
+@pytest.mark.parametrize("k", [300, 400, 16])
+def test_plan_forward_scores(rfm, monkeypatch, k):
+    """rfm_fm_plan_forward: the scores of an evaluation log through the plan -- by the sliced forward
+    where the plan has one (even k > 128; the log registered in slot 1 or translated per call), by the
+    plain forward otherwise -- against rfm_fm_forward and the oracle; rows longer than the records of
+    a translated row, empty rows."""
+    pkg, _lib, runtime, rt = rfm
+    from relevance_factorizationmachine_amd.fm import FmPlan
+    rng = np.random.default_rng(k)
+    train = _random_log(rng, 3000, 200, 0.05, 4)
+    a = _random_log(rng, 900, 200, 0.05, 4)
+    b = _random_log(rng, 100, 200, 0.6, 0)
+    X = vstack([a["features"], b["features"]]).tolil()
+    X[7, :] = 0
+    X = X.tocsr()
+    X.eliminate_zeros()
+    X.sort_indices()
+    monkeypatch.setenv("RFM_SLICED_MIN_ROWS", "1")
+    dev = runtime.DeviceCSR(rt, train["features"])
+    y = rt.upload(train["labels"], dtype=np.float64)
+    p = rt.upload(train["pscores"], dtype=np.float64)
+    ev = runtime.DeviceCSR(rt, X)
+    m = _fm(pkg, n_factors=k, n_features=200, seed=9)
+    params = (m.w0.dev.data_ptr(), m.w.dev.data_ptr(), m.V.dev.data_ptr())
+    plan = FmPlan(rt, dev, y, p, k, 1000)
+    assert (plan.sliced()["slices"] > 0) == (k > 128)
+    want = m.predict(X)
+    for registered in (False, True, False):
+        _lib.check(rt.lib.rfm_fm_plan_register_log(
+            rt.ctx, plan.handle, 1, *( (ev.indptr.data_ptr(), ev.indices.data_ptr(), ev.values.data_ptr(), 1000)
+                                       if registered else (None, None, None, 0))))
+        out = rt.empty((1000,), y.dtype)
+        _lib.check(rt.lib.rfm_fm_plan_forward(rt.ctx, plan.handle, ev.indptr.data_ptr(), ev.indices.data_ptr(),
+                                              ev.values.data_ptr(), 1000, *params, out.data_ptr()))
+        rt.sync()
+        got = out.cpu().numpy()
+        assert rel_err(got, want) < 1e-12
+        assert_elementwise(got, want, what="scores")
+    monkeypatch.delenv("RFM_SLICED_MIN_ROWS")
+    plan.close()
+    w0, w, V = cpu_ref.fm_init(9, 200, k)
+    assert rel_err(got, cpu_ref.fm_predict(X, w0, w, V)) < TIGHT

@@ -222,6 +222,7 @@ SlicedGeom sliced_geom(const rfm_ctx* ctx, const rfm_fm_plan* plan, int64_t rows
   SlicedGeom g;
   if (plan->sl_ns <= 0 || env_int("RFM_SLICED_LOSS", 1) == 0) return g;
   if (rows < std::max(1, env_int("RFM_SLICED_MIN_ROWS", 4096))) return g;
+  if (rows >= (int64_t(1) << 31) - 1) return g;  // (the kernel numbers a log's rows in 31 bits)
   const int xs = 8 / plan->sl_ns;
   int wps = std::max(xs, ctx->n_cu / plan->sl_ns / xs * xs);
   // (few rows: fewer, fuller workgroups -- each fills its own copy of the cached columns)

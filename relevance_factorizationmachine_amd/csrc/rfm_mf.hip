@@ -457,24 +457,29 @@ __global__ __launch_bounds__(seq_block(NC)) void mf_sgd_seq_ex_kernel(MfExArgs a
   mf_slot_fetch<LPR, VEC, NC, PF>(a, m, 1, g, l, 1, s1);
   mf_slot_fetch<LPR, VEC, NC, PF>(a, m, 2, g, l, 2, s2);
   mf_slot_fetch<LPR, VEC, NC, PF>(a, m, 3, g, l, 3, s3);
+#ifdef RFM_MF_PROBE_NOBARRIER  // timing probe only (results are NOT valid): no barrier between two one-example levels
+#define RFM_MF_SYNC(tt) do { const int t_ = (tt); if (!(t_ + 2 <= n_lev && lptr[t_ + 1] - lptr[t_] == 1 && lptr[t_ + 2] - lptr[t_ + 1] == 1)) __syncthreads(); } while (0)
+#else
+#define RFM_MF_SYNC(tt) __syncthreads()
+#endif
   for (int t = 0; t < n_lev; t += kMfAhead) {
     // the rows of level t+4 are read while level t is still running: final if the
     // previous writer lies before level t, i.e. more than four levels back
     mf_slot_run<LPR, VEC, NC>(a, m, l, s0);
     mf_slot_fetch<LPR, VEC, NC, PF>(a, m, t + 4, g, l, kMfAhead, s0);
-    __syncthreads();
+    RFM_MF_SYNC(t);
     if (t + 1 >= n_lev) break;
     mf_slot_run<LPR, VEC, NC>(a, m, l, s1);
     mf_slot_fetch<LPR, VEC, NC, PF>(a, m, t + 5, g, l, kMfAhead, s1);
-    __syncthreads();
+    RFM_MF_SYNC(t + 1);
     if (t + 2 >= n_lev) break;
     mf_slot_run<LPR, VEC, NC>(a, m, l, s2);
     mf_slot_fetch<LPR, VEC, NC, PF>(a, m, t + 6, g, l, kMfAhead, s2);
-    __syncthreads();
+    RFM_MF_SYNC(t + 2);
     if (t + 3 >= n_lev) break;
     mf_slot_run<LPR, VEC, NC>(a, m, l, s3);
     mf_slot_fetch<LPR, VEC, NC, PF>(a, m, t + 7, g, l, kMfAhead, s3);
-    __syncthreads();
+    RFM_MF_SYNC(t + 3);
   }
   __syncthreads();
   // write the cached item rows back

@@ -1,21 +1,23 @@
-// Loss forwards of fit() for factor counts of several chunks per lane (k > 128: every published
-// run of the reference is k = 400 or 300), sliced by FACTORS (gfx950).
+// Scoring forwards for factor counts of several chunks per lane (even k > 128: every published
+// run of the reference is k = 400 or 300), sliced by FACTORS (gfx950): the loss forwards of
+// rfm_fm_train and the scores of rfm_fm_plan_forward.
 //
 // Reference arithmetic: src/fm.py:114-133 (predict), src/base.py:37-66 (loss, clipped sigmoid).
 //
 // The pair term of the logit is a sum over factors, 0.5 * sum_f [(sum_e v_ef x_e)^2 -
 // sum_e (v_ef x_e)^2], so a slice of the factors contributes an independent partial logit.  A
-// workgroup owns ONE slice (ns slices of sw factors; the slices are dealt to the XCDs so that an
-// XCD's L2 only ever holds its slice of V) and a block of rows, and keeps the slice of the
-// log's most frequent columns (side features, dense reals, popular items: 13 of a row's 15
-// entries on the KuaiRec shape) in LDS: at k = 400 the plain forward is bound by gathering
-// 15 x 3 200 B per row from L2 (14 308 validation rows: 687 MB, 41 us = the guide's L2 gather
-// rate); here only the rare columns are gathered.  For a cached column the per-entry sum of
-// squares is x^2 |v_slice|^2 with the norm computed once per workgroup, so a cached entry costs
-// two FMAs per lane.
+// workgroup owns ONE slice (one slice per 256 factors -- a lane holds four; the slices are dealt
+// to the XCDs so that an XCD's L2 only ever holds its slice of V) and a block of rows, and keeps
+// the slice of the log's most frequent columns (side features, dense reals, popular items: 12 of
+// a row's 15 entries on the KuaiRec shape) in LDS: at k = 400 the plain forward is bound by
+// gathering 15 x 3 200 B per row from L2 (14 308 validation rows: 687 MB, 41 us = the guide's L2
+// gather rate); here only the rare columns are gathered.  For a cached column the per-entry sum
+// of squares is x^2 |v_slice|^2 with the norm computed once per workgroup, so a cached entry
+// costs one FMA per factor.
 //
 // The logs are read in a TRANSLATED form (sl_translate_kernel: the training log once per plan,
-// the validation log once per rfm_fm_train call): rows of 2^ml_log2 records {LDS offset of the
+// any other log once per call or once per registration, rfm_fm_plan_register_log): rows of
+// 2^ml_log2 records {LDS offset of the
 // column's cached slice, column, value} at a fixed stride, the cached columns' entries FIRST.  A
 // wavefront works on one row at a time, entry e in lane e: "entry j" is then a v_readlane with a
 // CONSTANT lane, the cached entries are lanes 0 .. n - 1, and an entry that is not cached points
@@ -26,7 +28,8 @@
 // stride are marked and read straight from the caller's CSR arrays (slow, correct).
 //
 // Output: zpart[slice][row]; slice 0 carries w0 + <w, x>.  The scores, the logarithms and the
-// sums over rows are left to loss_from_slices_kernel, once per RUN of iterations.
+// sums over rows are left to loss_from_slices_kernel, once per RUN of iterations (or to
+// scores_from_slices_kernel).  What bounds it, measured: VALU issue.
 #pragma once
 
 #include "rfm_fm_kernels.hpp"

@@ -100,3 +100,49 @@ def test_device_evaluator_with_ties_equals_numpy_ranking(n, n_users, k, levels, 
         return
     want = cpu_ref.val_dcg(frame, scores, "IPS", k=k)
     assert got == pytest.approx(want, rel=1e-12)
+
+
+@settings(max_examples=200, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(n_rows=st.integers(1, 700), n_val=st.integers(1, 500), n_cols=st.integers(1, 260),
+       density=st.floats(0.0, 0.6), half_k=st.integers(65, 300), frac=st.floats(0.05, 1.0),
+       dense_cols=st.integers(0, 4), seed=st.integers(0, 10 ** 6), hot=st.sampled_from([0, -1]))
+def test_sliced_loss_forward_random_shapes(n_rows, n_val, n_cols, density, half_k, frac, dense_cols, seed, hot):
+    """Even factor counts 130 .. 600 (one, two and four slices; any width of the last slice), logs of any
+    density (rows of zero to hundreds of entries: translated rows of 16 / 32 / 64 records and rows read
+    from the CSR arrays), any batch: the fit() loop with the sliced loss forward forced on
+    (RFM_SLICED_MIN_ROWS=1; the train-loss rows in it, the logarithms once per call) against the oracle --
+    parameters and both loss curves -- and the plan's scoring forward against predict()."""
+    import os
+
+    import relevance_factorizationmachine_amd as pkg
+    rng = np.random.default_rng(seed)
+    k = 2 * half_k
+
+    def log(m):
+        X = sprandom(m, n_cols, density=density, format="csr", random_state=rng,
+                     data_rvs=lambda s: rng.standard_normal(s)).tolil()
+        for c in range(min(dense_cols, n_cols)):
+            X[:, c] = rng.standard_normal(m)[:, None]
+        X = X.tocsr()
+        X.sort_indices()
+        return {"features": X, "labels": (rng.random(m) < 0.5).astype(np.int64),
+                "pscores": rng.uniform(0.1, 1.0, size=m) ** 0.5}
+
+    train, val = log(n_rows), log(n_val)
+    batch = max(1, int(round(frac * n_rows)))
+    kw = dict(n_epochs=2, n_factors=k, lr=1e-5, batch_size=batch, seed=seed % 1000)
+    old = os.environ.get("RFM_SLICED_MIN_ROWS")
+    os.environ["RFM_SLICED_MIN_ROWS"] = "1"
+    try:
+        model = pkg.FactorizationMachines(estimator="IPS", n_features=n_cols, **kw)
+        model.hot_min_count = hot
+        tr, va = model.fit(train, val)
+    finally:
+        if old is None:
+            del os.environ["RFM_SLICED_MIN_ROWS"]
+        else:
+            os.environ["RFM_SLICED_MIN_ROWS"] = old
+    assert model.plan_info["slices"] in ((1, 2, 4) if train["features"].nnz else (0,))  # (no entries: nothing to slice)
+    ref = cpu_ref.fm_fit(train, val, n_features=n_cols, **kw)
+    assert rel_err(model.V(), ref["V"]) < TIGHT and rel_err(model.w(), ref["w"]) < TIGHT
+    assert rel_err(tr, ref["train_loss"]) < TIGHT and rel_err(va, ref["val_loss"]) < TIGHT

@@ -341,6 +341,47 @@ def published_config(rt, only: str | None = None) -> dict:
                     "what": "nnz x (k+1) x 8 bytes of V / w rows gathered per launch of rfm_fm_forward on the "
                             "validation split, 100 back-to-back launches (wall / 100); peaks: MI355X guide, "
                             "'Indexed rows: gather' table"}
+        # both loss forwards of an iteration (the batch's rows with the new parameters + the validation
+        # split): at even k > 128 ONE launch sliced by factors that keeps the frequent columns' slices
+        # in LDS (csrc/rfm_fm_sliced.hpp) -- timed as (iterations with losses) - (iterations without),
+        # priced in the same model: the bytes the PLAIN forward would gather from L2
+        vy = rt.upload(val["labels"], dtype=np.float64)
+        vp = rt.upload(val["pscores"], dtype=np.float64)
+        plan2 = FmPlan(rt, csr, y, p, k, B)
+        tl = rt.empty((K,), torch.float64)
+        vl = rt.empty((K,), torch.float64)
+
+        def run_losses(first, count, losses):
+            _lib.check(rt.lib.rfm_fm_train(
+                rt.ctx, plan2.handle, *args, d_ids.data_ptr() + first * B * 4, B, count, *params, lr,
+                vcsr.indptr.data_ptr(), vcsr.indices.data_ptr(), vcsr.values.data_ptr(), vy.data_ptr(),
+                vp.data_ptr(), vX.shape[0], 1e-8, tl.data_ptr() if losses else None,
+                vl.data_ptr() if losses else None))
+        per = {}
+        for losses in (True, False):
+            run_losses(0, warm, losses)
+            regs = []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run_losses(warm, K, losses)
+                torch.cuda.synchronize()
+                regs.append((time.perf_counter() - t0) / K)
+            per[losses] = float(np.median(regs))
+        sliced_info = plan2.sliced()
+        plan2.close()
+        loss_gather = (int(vX.nnz) + int(B * z)) * (k + 1) * 8
+        loss_dt = max(per[True] - per[False], 1e-9)
+        loss_roof = {"rows": int(vX.shape[0]) + B, "ms_per_iteration": 1e3 * loss_dt,
+                     "form": ("sliced by factors: %d slices of %d factors, %d columns' slices in LDS"
+                              % (sliced_info["slices"], sliced_info["factors_per_slice"], sliced_info["cached_columns"]))
+                     if sliced_info["slices"] and vX.shape[0] + B >= 4096 else "plain forwards",
+                     "plain_model_gathered_bytes": loss_gather, "achieved": loss_gather / loss_dt / 1e9,
+                     "unit": "GB/s", "peak": L2_GATHER_GBS, "frac": loss_gather / loss_dt / 1e9 / L2_GATHER_GBS,
+                     "bound": "valu-issue (sliced) / l2-gather (plain)",
+                     "what": "(rfm_fm_train with both losses) - (without), 200 iterations each, median of 5; the bytes "
+                             "are what the plain forward gathers from L2 for these rows (nnz x (k+1) x 8): above 1.0 "
+                             "= faster than a forward that gathers every entry's row of V can be"}
         # the step's own L2 traffic in the same model: forward gathers, then every marked entry
         # re-reads its Q row and every distinct column's row of V is read and written once
         distinct = int(np.unique(X[sample_batches(X.shape[0], B, warm, 1)[0]].indices).shape[0])
@@ -408,6 +449,7 @@ def published_config(rt, only: str | None = None) -> dict:
                      "l2_bytes_per_step": step_l2, "l2_achieved_GBs": step_l2 / dt / 1e9,
                      "frac_of_l2_gather_peak": step_l2 / dt / 1e9 / L2_GATHER_GBS},
             "validation_forward_roofline": val_roof,
+            "loss_forwards_roofline": loss_roof,
             "fit_wall": {"iterations": its, "ms_per_iteration": 1e3 * walls["cold"] / its,
                          "value": its * B / walls["cold"], "unit": "examples/s",
                          "ms_per_iteration_second_fit_same_log": 1e3 * walls["again"] / its,

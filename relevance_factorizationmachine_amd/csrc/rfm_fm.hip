@@ -683,6 +683,9 @@ FwdArgs forward_args(const int64_t* d_indptr, const int32_t* d_indices, const do
   f.w = d_w;
   f.V = d_V;
   f.k = k;
+#ifdef RFM_ABLATE
+  f.ablate = env_int("RFM_ABLATE_MASK", 0);  // (timing experiments: bit 4 = every gather reads row 0 of V)
+#endif
   return f;
 }
 

@@ -18,7 +18,7 @@ SETTINGS = dict(max_examples=200, deadline=None, suppress_health_check=list(Heal
 @settings(**SETTINGS)
 @given(n_rows=st.integers(1, 900), n_cols=st.integers(1, 80), density=st.floats(0.0, 0.5),
        k=st.integers(1, 70), frac=st.floats(0.01, 1.0), hot=st.sampled_from([0, -1, 1, 8]),
-       dense_cols=st.integers(0, 3), seed=st.integers(0, 10 ** 6), epochs=st.integers(1, 3))
+       dense_cols=st.integers(0, 3), seed=st.integers(0, 10 ** 6), epochs=st.integers(1, 6))
 def test_fm_fit_random_shapes(n_rows, n_cols, density, k, frac, hot, dense_cols, seed, epochs):
     import relevance_factorizationmachine_amd as pkg
     rng = np.random.default_rng(seed)

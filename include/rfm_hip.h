@@ -281,7 +281,8 @@ int32_t rfm_fm_set_rows(rfm_ctx* ctx, const double* d_rows, int64_t n_rows,
  * (default 4 096; RFM_SLICED_LOSS=0: never) -- same losses up to the order of the sums.  The
  * other loss forwards leave their rows' scores and one launch per run of iterations takes the
  * logarithms (RFM_DEFER_LOSS=0: inside the forward); at small batches the train-loss rows of an
- * iteration are scored inside the NEXT iteration's forward launch (RFM_RIDE_LOSS=0: apart).
+ * iteration are scored inside the NEXT iteration's forward launch (RFM_RIDE_LOSS=0: apart), and so
+ * are the rows of a small validation log registered with rfm_fm_plan_register_log (RFM_RIDE_VAL=0).
  * (Environment, experiments only: RFM_PREP=1 at plan creation
  * makes calls of 8 or more iterations lay their batches out ahead of the loop -- same results bit
  * for bit, one wait on an event per chunk of iterations; RFM_TRAIN_GRAPH=1 replays the call's

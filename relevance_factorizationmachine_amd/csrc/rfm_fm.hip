@@ -310,9 +310,13 @@ struct PrepView {
 // the three launches of one step; grad == nullptr -> update in place
 // rows of the plan's log that a step's forward launch scores on the side (fm_forward_kernel, XTRA)
 struct XtraRows {
-  const int32_t* ids;
+  const int32_t* ids;  // rows ids[0 .. n) of the plan's log ...
   int64_t n;
   double* out_pred;
+  const RowRec* rows_y;  // ... and every row of another log given as records (n_y = 0: none)
+  const Entry* ent_y;
+  int64_t n_y;
+  double* out_pred_y;
 };
 // whether a step of `batch` rows can take them along: the one-row forward shape, arrival-order hot
 // sums, rows through the plan's records
@@ -383,10 +387,20 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
     const FwdGeom gx = forward_geom(ctx, xtra->n, s, true);
     RFM_REQUIRE(gx.block == kSmallBlock, "extra rows: unexpected geometry");
     f.grid_main = geom.grid;
+    f.grid_x = gx.grid;
     f.row_ids_x = xtra->ids;
     f.n_rows_x = xtra->n;
     f.out_pred_x = xtra->out_pred;
     launch.grid = geom.grid + gx.grid;
+    if (xtra->n_y > 0) {
+      const FwdGeom gy = forward_geom(ctx, xtra->n_y, s, true);
+      RFM_REQUIRE(gy.block == kSmallBlock && f.ent && f.rows, "extra log: unexpected geometry / plan form");
+      f.rows_y = xtra->rows_y;
+      f.ent_y = xtra->ent_y;
+      f.n_rows_y = xtra->n_y;
+      f.out_pred_y = xtra->out_pred_y;
+      launch.grid += gy.grid;
+    }
   }
   ctx->prof_mark();
 #ifdef RFM_ABLATE
@@ -1143,6 +1157,14 @@ void train_loop(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr, const 
     // its own.  A run's logarithms then wait for the next step's launch.  (RFM_RIDE_LOSS=0: never.)
     const bool ride = scores_only && d_out_train_loss && step_takes_extra_rows(ctx, plan, batch) &&
                       !(prepared.on && !prepared.records_only) && env_int("RFM_RIDE_LOSS", 1) != 0;
+    // ... and so may the validation rows (the same parameters again), when the caller has registered
+    // the log (rfm_fm_plan_register_log keeps it as records), it takes the one-row shape too, and the
+    // plan holds plain records (RFM_RIDE_VAL=0: never)
+    const rfm_fm_plan::SlLog& vlog = plan->sl_log[0];
+    const bool ride_val = ride && d_out_val_loss && vlog.records &&
+                          vlog.holds(d_val_indptr, d_val_indices, d_val_values, n_val) && plan->ent.p &&
+                          !plan->ell.p && forward_geom(ctx, n_val, shape_for(plan->k), true).block == kSmallBlock &&
+                          env_int("RFM_RIDE_VAL", 1) != 0;
     int64_t run_first = 0, pending_first = -1, pending_count = 0;
     for (int64_t it = 0; it < n_iters; ++it) {
       const int32_t* ids = d_ids + it * batch;
@@ -1152,7 +1174,11 @@ void train_loop(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr, const 
       XtraRows prev{};
       if (ride && it > 0) {
         const int64_t prev_slot = pending_count > 0 ? pending_count - 1 : slot - 1;
-        prev = XtraRows{ids - batch, batch, plan->sl_z.as<double>() + prev_slot * z_per_iter};
+        double* zs = plan->sl_z.as<double>() + prev_slot * z_per_iter;
+        prev = XtraRows{ids - batch, batch, zs, nullptr, nullptr, 0, nullptr};
+        if (ride_val)
+          prev = XtraRows{ids - batch, batch, zs, vlog.rows_rec.as<RowRec>(), vlog.ent_rec.as<Entry>(),
+                          n_val, zs + sl_a};
       }
       enqueue_step(ctx, plan, d_indptr, d_indices, d_values, d_y, d_pscore, ids, batch, d_w0,
                    d_w, d_V, lr, nullptr, nullptr, 0, is_prepared ? &pv : nullptr,
@@ -1227,7 +1253,7 @@ void train_loop(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr, const 
           train_parts = forward_loss_deferred(ctx, f, train_rows + slot * kMaxFwdGrid);
         }
       }
-      if (d_out_val_loss && !merged) {
+      if (d_out_val_loss && !merged && !(ride_val && it + 1 < n_iters)) {
         FwdArgs f = forward_args(d_val_indptr, d_val_indices, d_val_values, nullptr, n_val,
                                  d_w0, d_w, d_V, plan->k);
         f.eps = eps;

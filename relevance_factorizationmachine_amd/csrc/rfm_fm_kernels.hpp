@@ -158,6 +158,13 @@ struct FwdArgs {
   const int32_t* row_ids_x;
   int64_t n_rows_x;
   double* out_pred_x;
+  // ... and, after grid_x of those, workgroups that score EVERY row of another log given as row and
+  // entry records (the validation log: rfm_fm_plan_register_log) -> out_pred_y
+  int32_t grid_x;
+  const RowRec* rows_y;
+  const Entry* ent_y;
+  int64_t n_rows_y;
+  double* out_pred_y;
 };
 
 #ifdef RFM_ABLATE
@@ -197,10 +204,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
   unsigned bx = blockIdx.x, gx = gridDim.x;
   if constexpr (XTRA && REC) {
     if (int(blockIdx.x) >= a.grid_main) {
-      bx = blockIdx.x - a.grid_main;
-      gx = gridDim.x - a.grid_main;
-      a.row_ids = a.row_ids_x;
-      a.n_rows = a.n_rows_x;
+      const bool second = int(blockIdx.x) >= a.grid_main + a.grid_x;
+      bx = blockIdx.x - a.grid_main - (second ? a.grid_x : 0);
+      gx = second ? gridDim.x - a.grid_main - a.grid_x : a.grid_x;
+      a.row_ids = second ? nullptr : a.row_ids_x;
+      a.n_rows = second ? a.n_rows_y : a.n_rows_x;
+      if (second) {
+        a.rows = a.rows_y;
+        a.ent = a.ent_y;
+      }
       a.n_hot = 0;
       a.slot_mark = nullptr;
       a.slot_bits = nullptr;
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
       a.out_err = nullptr;
       a.err_partial = nullptr;
       a.loss_partial = nullptr;
-      a.out_pred = a.out_pred_x;
+      a.out_pred = second ? a.out_pred_y : a.out_pred_x;
     } else {
       gx = a.grid_main;
     }

@@ -38,6 +38,9 @@ struct rfm_fm_plan {
   // one iteration per call and scores an evaluation log after each)
   struct SlLog {
     rfm::DevBuf tr;
+    rfm::DevBuf rows_rec, ent_rec;  // slot 0: the log as RowRec / Entry records (what the step's
+                                    // forward launch reads when the validation rows ride in it)
+    bool records = false;
     const void* indptr = nullptr;
     const void* indices = nullptr;
     const void* values = nullptr;

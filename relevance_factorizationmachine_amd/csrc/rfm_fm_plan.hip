@@ -160,6 +160,17 @@ __global__ __launch_bounds__(kBlock) void sl_translate_kernel(const int64_t* ind
   }
 }
 
+// a log as the records the forward kernel's REC form reads (labels / propensities unused: 0 / 1)
+__global__ __launch_bounds__(kBlock) void log_records_kernel(const int64_t* indptr, const int32_t* indices,
+                                                           const double* values, int64_t n_rows,
+                                                           RowRec* rows, Entry* ent) {
+  for (int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x; r < n_rows; r += int64_t(gridDim.x) * kBlock) {
+    const int64_t b = indptr[r], e = indptr[r + 1];
+    rows[r] = RowRec{b, e - b, 0.0, 1.0};
+    for (int64_t q = b; q < e; ++q) ent[q] = Entry{indices[q], 0, values[q]};
+  }
+}
+
 void upload(DevBuf& dst, const void* src, size_t bytes, hipStream_t stream) {
   dst.alloc(bytes);
   if (bytes) RFM_HIP_CHECK(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, stream));
@@ -587,8 +598,24 @@ int32_t rfm_fm_plan_register_log(rfm_ctx* ctx, rfm_fm_plan* plan, int32_t slot, 
     RFM_REQUIRE(ctx && plan && (slot == 0 || slot == 1), "null pointer / slot outside 0..1");
     rfm_fm_plan::SlLog& log = plan->sl_log[slot];
     log.rows = -1;
-    if (plan->sl_ns <= 0 || n_rows <= 0 || !d_indptr) return;  // (nothing to keep)
-    sliced_translate(ctx, plan, d_indptr, d_indices, d_values, n_rows, log.tr);
+    log.records = false;
+    if (n_rows <= 0 || !d_indptr) return;  // (nothing to keep)
+    if (plan->sl_ns > 0) sliced_translate(ctx, plan, d_indptr, d_indices, d_values, n_rows, log.tr);
+    if (slot == 0 && n_rows < (int64_t(1) << 31)) {  // the validation log as records (it may ride, rfm_fm_train)
+      int64_t nnz = 0;
+      RFM_HIP_CHECK(hipMemcpyAsync(&nnz, d_indptr + n_rows, 8, hipMemcpyDeviceToHost, ctx->stream));
+      RFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      if (nnz >= 0 && nnz < (int64_t(1) << 31) - 2) {
+        log.rows_rec.ensure(size_t(n_rows) * sizeof(RowRec));
+        log.ent_rec.ensure(size_t(nnz + 1) * sizeof(Entry));
+        RFM_HIP_CHECK(hipMemsetAsync(log.ent_rec.as<Entry>() + nnz, 0, sizeof(Entry), ctx->stream));
+        hipLaunchKernelGGL(log_records_kernel, dim3(grid_for(ctx, n_rows)), dim3(kBlock), 0, ctx->stream,
+                           d_indptr, d_indices, d_values, n_rows, log.rows_rec.as<RowRec>(),
+                           log.ent_rec.as<Entry>());
+        RFM_HIP_CHECK(hipGetLastError());
+        log.records = true;
+      }
+    }
     log.indptr = d_indptr;
     log.indices = d_indices;
     log.values = d_values;

@@ -1201,20 +1201,24 @@ def test_deferred_loss_logarithms_give_the_same_losses(rfm, monkeypatch, shape, 
     fits = {}
     monkeypatch.setenv("RFM_SLICED_LOSS", "0")
     monkeypatch.setenv("RFM_MERGE_LOSS", "0")
-    for mode, defer, ride in (("0", "0", "1"), ("1", "1", "1"), ("apart", "1", "0")):
+    for mode, defer, ride, ride_val in (("0", "0", "1", "1"), ("1", "1", "1", "1"), ("apart", "1", "0", "1"),
+                                        ("train_only", "1", "1", "0")):
         monkeypatch.setenv("RFM_DEFER_LOSS", defer)
         monkeypatch.setenv("RFM_RIDE_LOSS", ride)
+        monkeypatch.setenv("RFM_RIDE_VAL", ride_val)
         m = pkg.FactorizationMachines(estimator="IPS", n_epochs=its, n_factors=k, lr=9e-6, batch_size=batch,
                                       seed=12345, n_features=train["features"].shape[1])
         m.hot_min_count = -1  # (no on-chip class: every sum in a fixed order, and the rows may ride)
         fits[mode] = (m, *m.fit(train, val))
-    for name in ("RFM_DEFER_LOSS", "RFM_RIDE_LOSS", "RFM_SLICED_LOSS", "RFM_MERGE_LOSS"):
+    for name in ("RFM_DEFER_LOSS", "RFM_RIDE_LOSS", "RFM_RIDE_VAL", "RFM_SLICED_LOSS", "RFM_MERGE_LOSS"):
         monkeypatch.delenv(name)
     (a, tra, vaa), (b, trb, vab), (c, trc, vac) = fits["0"], fits["1"], fits["apart"]
-    # (the train-loss rows riding in the next step's forward launch -- small batches -- or scored by a
-    # launch of their own: the same scores, bit for bit)
+    # (the train-loss rows -- and the registered validation log's -- riding in the next step's forward
+    # launch at small batches, or scored by launches of their own: the same scores, bit for bit)
     np.testing.assert_array_equal(np.asarray(trb), np.asarray(trc))
     np.testing.assert_array_equal(np.asarray(vab), np.asarray(vac))
+    np.testing.assert_array_equal(np.asarray(vab), np.asarray(fits["train_only"][2]))
+    np.testing.assert_array_equal(np.asarray(trb), np.asarray(fits["train_only"][1]))
     np.testing.assert_array_equal(a.V(), b.V())
     np.testing.assert_array_equal(c.V(), b.V())
     assert len(trb) == its and rel_err(trb, tra) < 1e-13 and rel_err(vab, vaa) < 1e-13

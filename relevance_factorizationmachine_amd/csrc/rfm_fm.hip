@@ -402,12 +402,49 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
       launch.grid += gy.grid;
     }
   }
+#ifdef RFM_FWD_STAMPS
+  // timing builds: clock readings of the many-rows forward, printed for the 60th step of the plan
+  static DevBuf fwd_stamps;
+  const size_t stamp_count = size_t(launch.grid) * (launch.block / kWave) * 2 * 8;
+  if (env_int("RFM_FWD_STAMPS", 0)) {
+    fwd_stamps.ensure(stamp_count * 8);
+    RFM_HIP_CHECK(hipMemsetAsync(fwd_stamps.p, 0, stamp_count * 8, ctx->stream));
+    f.stamps = static_cast<long long*>(fwd_stamps.p);
+  }
+#endif
   ctx->prof_mark();
 #ifdef RFM_ABLATE
   if (!(f.ablate & 64))
 #endif
     launch_forward(ctx, f, launch);
   ctx->prof_mark();
+#ifdef RFM_FWD_STAMPS
+  if (f.stamps && plan->step == 59) {
+    std::vector<long long> h(stamp_count);
+    RFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    RFM_HIP_CHECK(hipMemcpy(h.data(), fwd_stamps.p, stamp_count * 8, hipMemcpyDeviceToHost));
+    const int waves = launch.block / kWave;
+    for (int wv : {0, waves / 2, waves - 1}) {
+      double d[2][8] = {{0}}, n = 0;
+      for (int b = 0; b < launch.grid; ++b) {
+        const long long* t0 = &h[((size_t(b) * waves + wv) * 2 + 0) * 8];
+        const long long* t1 = t0 + 8;
+        if (!t0[0] || !t1[6]) continue;
+        for (int i = 0; i < 8; ++i) {
+          d[0][i] += t0[i] ? double(t0[i] - t0[0]) : 0.0;
+          d[1][i] += t1[i] ? double(t1[i] - t0[0]) : 0.0;
+        }
+        n += 1;
+      }
+      if (n > 0)
+        fprintf(stderr, "[forward stamps] wave %2d over %.0f workgroups, clocks since entry -- trip 0: rows in %.0f, gathers summed %.0f, "
+                        "scores out %.0f, marks + hot adds %.0f | trip 1: start %.0f, rows in %.0f, gathers %.0f, scores %.0f, hot %.0f | "
+                        "trips done %.0f, end %.0f\n",
+                wv, n, d[0][1] / n, d[0][2] / n, d[0][3] / n, d[0][4] / n, d[1][0] / n, d[1][1] / n, d[1][2] / n, d[1][3] / n,
+                d[1][4] / n, d[1][5] / n, d[1][6] / n);
+    }
+  }
+#endif
 
   if (d_grad && !d_touch) {  // dense gradient: every element is written
     const size_t bytes = (size_t(plan->n_features) * (k + 1) + 1) * sizeof(double);

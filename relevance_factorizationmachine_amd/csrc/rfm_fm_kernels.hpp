@@ -165,6 +165,9 @@ struct FwdArgs {
   const Entry* ent_y;
   int64_t n_rows_y;
   double* out_pred_y;
+#ifdef RFM_FWD_STAMPS
+  long long* stamps;  // -DRFM_FWD_STAMPS builds only: [workgroup][wave][trip 0/1][8] clock readings
+#endif
 };
 
 #ifdef RFM_ABLATE
@@ -273,9 +276,30 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
       for (int i = tid; i < H * NW; i += BLOCK) hbits[i] = 0u;
     __syncthreads();
   }
+  // The wavefronts of a workgroup run their trips in lockstep: all sixteen gather (memory latency,
+  // LDS idle), then all sixteen add their hot entries (LDS atomics saturated, nobody gathers).  Half
+  // of them starting one gather phase late puts the two kinds of work side by side
+  // (RFM_FWD_STAGGER = the delay in units of 64 clocks; 0: none).
+#ifndef RFM_FWD_STAGGER
+#define RFM_FWD_STAGGER 0
+#endif
+  if constexpr (RFM_FWD_STAGGER > 0 && REC && BLOCK == kBigBlock) {
+    if (H > 0 && tid / kWave >= BLOCK / kWave / 2) {
+#pragma unroll
+      for (int i = 0; i < (RFM_FWD_STAGGER + 126) / 127; ++i)
+        __builtin_amdgcn_s_sleep(RFM_FWD_STAGGER < 127 ? RFM_FWD_STAGGER : 127);
+    }
+  }
 
+#ifdef RFM_FWD_STAMPS
+  int trip_no = 0;
+#define RFM_FSTAMP(i) do { if (a.stamps && (tid & (kWave - 1)) == 0 && trip_no < 2) a.stamps[((int64_t(blockIdx.x) * (BLOCK / kWave) + tid / kWave) * 2 + trip_no) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RFM_FSTAMP(i) do { } while (0)
+#endif
   for (int64_t base = int64_t(bx) * (GPB * R); base < a.n_rows;
        base += int64_t(gx) * (GPB * R)) {
+    RFM_FSTAMP(0);
     int64_t t[R];
     int32_t r[R];  // rows of a log (or of a batch) fit 31 bits
     // entry offsets: the plan checks that they fit 31 bits; the caller's CSR is taken as it is
@@ -372,6 +396,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
         if (l == 0) parked[i * GPB + g] = nxt[i];
     }
 
+    RFM_FSTAMP(1);  // (row blocks have arrived: maxlen is known)
     double q[R][NC][VEC];
     double s2[R], lin[R], err[R];
 #pragma unroll
@@ -448,6 +473,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
       }
     }
 
+    RFM_FSTAMP(2);  // (gathers summed)
     if (warm) {  // back from LDS (same wave wrote them): the gathers' registers are free again
 #pragma unroll
       for (int i = 0; i < R; ++i) nxt[i] = parked[i * GPB + g];
@@ -523,6 +549,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
       }
     }
     ++trip;
+    RFM_FSTAMP(3);  // (scores, residuals, Q rows out)
 
     int32_t touched[R];
     if (warm) {
@@ -746,7 +773,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
 #pragma unroll
       for (int i = 0; i < R; ++i) asm volatile("" ::"v"(touched[i]));  // keep the touches alive
     }
+    RFM_FSTAMP(4);  // (marks left, hot entries added)
+#ifdef RFM_FWD_STAMPS
+    ++trip_no;
+#endif
   }
+#ifdef RFM_FWD_STAMPS
+  trip_no = 1;
+#endif
+  RFM_FSTAMP(5);  // (all trips done)
 
   if (H > 0 && RFM_KEEP(a, 16)) {
     __syncthreads();
@@ -768,6 +803,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kBigBlock ? RFM_FWD_BIG_WAVES : 1)
     const double s = block_sum<BLOCK>(loss_acc2, red);
     if (tid == 0) a.loss_partial2[bx] = s;
   }
+  RFM_FSTAMP(6);  // (slab and partial sums stored)
 }
 
 // loss = -(sum of partials)/n, fixed order

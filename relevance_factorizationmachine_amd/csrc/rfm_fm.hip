@@ -483,6 +483,15 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
       c.err = plan->err.as<double>();
     }
     const int grid = c.nb_tasks + c.n_hot + 1;  // tasks, then the hot columns, then w0
+#ifdef RFM_CONS_STAMPS
+    static DevBuf cons_stamps;
+    const size_t cstamp_count = size_t(grid) * 8 * (kBlock / kWave) * 8;  // (x chunks at most 8)
+    if (env_int("RFM_CONS_STAMPS", 0)) {
+      cons_stamps.ensure(cstamp_count * 8);
+      RFM_HIP_CHECK(hipMemsetAsync(cons_stamps.p, 0, cstamp_count * 8, ctx->stream));
+      c.stamps = static_cast<long long*>(cons_stamps.p);
+    }
+#endif
     // LDS: the groups' lists + parked records + head rows, or the hot workgroups' scratch
     const int gpb = kBlock / s.lpr;
     const int win = s.lpr >= 32 ? 64 : 4 * s.lpr;  // WinShape<LPR>::WIN
@@ -524,6 +533,50 @@ void enqueue_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
       }
       RFM_HIP_CHECK(hipGetLastError());
     }
+#ifdef RFM_CONS_STAMPS
+    if (c.stamps && plan->step == 60) {  // timing builds: the task workgroups' clock readings of the 60th step
+      std::vector<long long> h(cstamp_count);
+      RFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      RFM_HIP_CHECK(hipMemcpy(h.data(), cons_stamps.p, cstamp_count * 8, hipMemcpyDeviceToHost));
+      const int waves = kBlock / kWave;
+      double d[8] = {0}, n = 0, life_max = 0;
+      long long t_first = 0, t_last = 0;
+      for (size_t b = 0; b < cstamp_count / 8 / waves; ++b) {
+        for (int wv = 0; wv < waves; ++wv) {
+          const long long* t = &h[(b * waves + wv) * 8];
+          if (!t[0] || !t[4]) continue;
+          for (int i = 1; i < 5; ++i) d[i] += double(t[i] - t[0]);
+          life_max = std::max(life_max, double(t[4] - t[0]));
+          t_first = t_first ? std::min(t_first, t[0]) : t[0];
+          t_last = std::max(t_last, t[4]);
+          n += 1;
+        }
+      }
+      if (n > 0)
+        fprintf(stderr, "[consume stamps] %.0f task wavefronts, clocks since their entry: slots listed %.0f, chain run %.0f, "
+                        "barrier %.0f, combined %.0f (longest life %.0f)\n",
+                n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, life_max);
+      (void)t_first;
+      (void)t_last;
+      // ... and of the wavefronts that live longer than 0.7 of the longest: which workgroups, which phase
+      double e[8] = {0}, m = 0, bsum = 0, bmin = 1e18, bmax = 0;
+      for (size_t b = 0; b < cstamp_count / 8 / waves; ++b) {
+        for (int wv = 0; wv < waves; ++wv) {
+          const long long* t = &h[(b * waves + wv) * 8];
+          if (!t[0] || !t[4] || double(t[4] - t[0]) < 0.7 * life_max) continue;
+          for (int i = 1; i < 5; ++i) e[i] += double(t[i] - t[0]);
+          bsum += double(b);
+          bmin = std::min(bmin, double(b));
+          bmax = std::max(bmax, double(b));
+          m += 1;
+        }
+      }
+      if (m > 0)
+        fprintf(stderr, "[consume stamps]   the %.0f longest-lived: listed %.0f, chain run %.0f, barrier %.0f, combined %.0f; "
+                        "workgroups %.0f .. %.0f (mean %.0f) of %d\n",
+                m, e[1] / m, e[2] / m, e[3] / m, e[4] / m, bmin, bmax, bsum / m, grid);
+    }
+#endif
   }
   ctx->prof_mark();
   // columns cut into several tasks (none on most plans): their partial rows

@@ -974,6 +974,9 @@ struct ConsArgs {
   const PrepRec* prep_rec;    // [tasks][kPrepCap]
   const int32_t* prep_cnt;    // [tasks]
   const double* err;          // [batch]
+#ifdef RFM_CONS_STAMPS
+  long long* stamps;  // -DRFM_CONS_STAMPS builds only: [workgroup][wave][8] clock readings of the task workgroups
+#endif
 };
 
 template <int VEC, int NC>
@@ -1180,6 +1183,12 @@ __global__ __launch_bounds__(kBlock, (CH && RFM_CONS_CH_WAVES > 0 ? RFM_CONS_CH_
   (void)kHotBytes;
   const int lane = threadIdx.x % kWave;
   const int l = lane % LPR;
+#ifdef RFM_CONS_STAMPS
+#define RFM_CSTAMP(i) do { if (a.stamps && (threadIdx.x & (kWave - 1)) == 0) a.stamps[(int64_t(blockIdx.x) * (kBlock / kWave) + threadIdx.x / kWave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RFM_CSTAMP(i) do { } while (0)
+#endif
+  RFM_CSTAMP(0);
   const int gb = threadIdx.x / LPR;  // group in the workgroup
   const int task = bx * GPB + gb;
   const int W = a.task_words;
@@ -1380,7 +1389,9 @@ __global__ __launch_bounds__(kBlock, (CH && RFM_CONS_CH_WAVES > 0 ? RFM_CONS_CH_
       if (__ballot(word != 0ull)) run_list();
     }
   }
+  RFM_CSTAMP(1);  // (bitmap words in, marked slots listed)
   if (!PREP && __ballot(fill > 0)) run_list();
+  RFM_CSTAMP(2);  // (chain run: records, Q / V rows, sums, columns inside the task updated)
 
   // ---- columns that run over several tasks of this workgroup -----------------------------
   // the last column of a tail-open task is still in `acc` (if it got any entry here); a
@@ -1400,6 +1411,7 @@ __global__ __launch_bounds__(kBlock, (CH && RFM_CONS_CH_WAVES > 0 ? RFM_CONS_CH_
   if (head_open && l == 0) head[k + 2] = (head_done ? 1.0 : 0.0) + (through ? 2.0 : 0.0);
   if (!head_open && l == 0) head[k + 2] = 0.0;
   __syncthreads();
+  RFM_CSTAMP(3);
   if (own) {
     if (!own_acc) {
       acc.clear();
@@ -1449,6 +1461,7 @@ __global__ __launch_bounds__(kBlock, (CH && RFM_CONS_CH_WAVES > 0 ? RFM_CONS_CH_
                                  a.touch, a.touch_id, fb);
     }
   }
+  RFM_CSTAMP(4);  // (columns that run over several tasks combined)
 }
 
 // ---------------------------------------------------------------------------

@@ -997,6 +997,18 @@ struct ColAcc {
 // gradient row (grad mode).  vold = the row as it was read before.
 // (fb: first factor of the chunk this lane group works on -- 0 unless the chunks of a row are
 // dealt to different workgroups; the scalar part, w / touch, is then written by chunk 0)
+// *p += x by its only writer of the step.  As `*p += x` the wavefront stands still for the load of *p
+// (nothing else waits for it) -- once per finished column in the gradient launch, eight times per task
+// where columns are short, and one dependent level in the finalize; the no-return atomic add gives the
+// same sum without the wait (-DRFM_W_RMW=1: the read-modify-write, for timing).
+__device__ inline void add_by_only_writer(double* p, double x) {
+#if defined(RFM_W_RMW) && RFM_W_RMW
+  *p += x;
+#else
+  unsafeAtomicAdd(p, x);
+#endif
+}
+
 template <int LPR, int VEC, int NC>
 __device__ inline void apply_column(const ColAcc<VEC, NC>& acc, const Pack<VEC> (&vold)[NC],
                                     int32_t col, double* V, double* w, double* grad, int64_t n,
@@ -1024,7 +1036,7 @@ __device__ inline void apply_column(const ColAcc<VEC, NC>& acc, const Pack<VEC> 
       grad[n * k + col] = -acc.gw;
       if (touch) touch[col] = touch_id;  // touched-row mode: the row is valid for this step
     } else {
-      w[col] += lr * acc.gw;
+      add_by_only_writer(w + col, lr * acc.gw);
     }
   }
 }
@@ -1053,7 +1065,7 @@ __device__ inline void apply_column_block(const double* tot, int32_t col, double
       grad[n * k + col] = -gw;
       if (touch) touch[col] = touch_id;
     } else {
-      w[col] += lr * gw;
+      add_by_only_writer(w + col, lr * gw);
     }
   }
 }
@@ -1175,7 +1187,7 @@ __global__ __launch_bounds__(kBlock, (CH && RFM_CONS_CH_WAVES > 0 ? RFM_CONS_CH_
         if (a.grad)
           a.grad[a.n * k + a.n] = -s;
         else
-          a.w0[0] += a.lr * s;
+          add_by_only_writer(a.w0, a.lr * s);
       }
     }
     return;
@@ -1651,7 +1663,7 @@ __global__ __launch_bounds__(kBlock) void fm_finalize_chunk_kernel(FinArgs a, in
       a.grad[a.n * k + cc.col] = -gw;
       if (a.touch) a.touch[cc.col] = a.touch_id;
     } else {
-      a.w[cc.col] += a.lr * gw;
+      add_by_only_writer(a.w + cc.col, a.lr * gw);
     }
   }
 }

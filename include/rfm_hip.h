@@ -208,7 +208,10 @@ int32_t rfm_fm_plan_hot_columns(const rfm_fm_plan* plan, int32_t* h_out, int32_t
  * contributions, and an id outside the log would index the records out of
  * bounds.  The calls do not check this by default; with the environment
  * variable RFM_CHECK_IDS=1 they validate the ids on the device first (this
- * synchronises the stream) and return RFM_ERR_BAD_ARG. */
+ * synchronises the stream) and return RFM_ERR_BAD_ARG.
+ * d_w0 / d_w / d_V: ordinary device memory (hipMalloc -- what a torch device tensor is): every
+ * element has ONE writer per step, which adds to w0 / w[col] with a hardware f64 atomic add that
+ * returns nothing (no wait for the old value); fine-grained / host-mapped memory is not supported. */
 int32_t rfm_fm_step(rfm_ctx* ctx, rfm_fm_plan* plan, const int64_t* d_indptr,
                     const int32_t* d_indices, const double* d_values, const double* d_y,
                     const double* d_pscore, const int32_t* d_row_ids, int64_t batch,
